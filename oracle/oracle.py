@@ -1,0 +1,160 @@
+"""ctypes loader for the CPU oracle (``oracle/cosim_oracle.c``).  TEST INFRASTRUCTURE.
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg import this
+module.  It also holds the numpy restatement of the reference's pure-Python per-step pieces
+(delay filter, observation assembly, wrappers) that the HIP path is checked against; each
+function cites the reference lines it follows and is itself pinned by ``tests/golden/``.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+from typing import Dict, Optional
+
+import numpy as np
+
+_DIR = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_DIR, "libcosim_oracle.so")
+_lib = None
+
+
+def build(force: bool = False) -> str:
+    src = os.path.join(_DIR, "cosim_oracle.c")
+    hdr = os.path.join(_DIR, "..", "include", "cosim_model.h")
+    stale = (not os.path.isfile(_LIB_PATH)) or any(
+        os.path.isfile(p) and os.path.getmtime(p) > os.path.getmtime(_LIB_PATH) for p in (src, hdr))
+    if force or stale:
+        subprocess.check_call(["make", "-C", _DIR, "-B", "libcosim_oracle.so"], stdout=subprocess.DEVNULL)
+    return _LIB_PATH
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = ctypes.CDLL(_LIB_PATH)
+        L.oracle_new.restype = ctypes.c_void_p
+        L.oracle_new.argtypes = [ctypes.c_void_p] * 5
+        L.oracle_free.argtypes = [ctypes.c_void_p]
+        L.oracle_ptr.restype = ctypes.POINTER(ctypes.c_double)
+        L.oracle_ptr.argtypes = [ctypes.c_void_p, ctypes.c_char_p]
+        L.oracle_int.argtypes = [ctypes.c_void_p, ctypes.c_char_p]
+        L.oracle_model.restype = ctypes.c_void_p
+        L.oracle_model.argtypes = [ctypes.c_void_p]
+        L.oracle_forward.argtypes = [ctypes.c_void_p]
+        L.oracle_step.argtypes = [ctypes.c_void_p]
+        L.oracle_cfrc_ext.argtypes = [ctypes.c_void_p]
+        L.oracle_reset.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+        L.oracle_contact.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+        L.oracle_control_step.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+        L.oracle_ray_down.restype = ctypes.c_double
+        L.oracle_ray_down.argtypes = [ctypes.c_void_p, ctypes.c_double, ctypes.c_double, ctypes.c_double]
+        _lib = L
+    return _lib
+
+
+_SHAPES = {
+    "qpos": ("nq",), "qvel": ("nv",), "qacc": ("nv",), "qacc_warmstart": ("nv",), "ctrl": ("nu",),
+    "xpos": ("nbody", 3), "xquat": ("nbody", 4), "xmat": ("nbody", 9), "xipos": ("nbody", 3),
+    "subtree_com": ("nbody", 3), "cinert": ("nbody", 10), "cvel": ("nbody", 6), "cfrc_ext": ("nbody", 6),
+    "qfrc_bias": ("nv",), "qfrc_passive": ("nv",), "qfrc_actuator": ("nv",), "qfrc_smooth": ("nv",),
+    "qacc_smooth": ("nv",), "qfrc_constraint": ("nv",),
+    "sensor_quat": (4,), "sensor_gyro": (3,), "sensor_vel": (3,),
+}
+
+
+class Oracle:
+    """One environment instance of the fp64 restatement."""
+
+    def __init__(self, compiled, body_mass: Optional[np.ndarray] = None):
+        from cosim_amd.compile import env_constants
+        from cosim_amd.model import CosimModel
+        self.L = lib()
+        assert self.L.oracle_model_sizeof() == ctypes.sizeof(CosimModel), "cosim_model_t layout mismatch"
+        self.cm = compiled
+        self._hv = np.ascontiguousarray(compiled.hull_vert, dtype=np.float32)
+        self._ha = np.ascontiguousarray(compiled.hull_adr, dtype=np.int32)
+        self._hn = np.ascontiguousarray(compiled.hull_nbr, dtype=np.int32)
+        self._hf = np.ascontiguousarray(compiled.hfield, dtype=np.float32)
+        self.h = self.L.oracle_new(ctypes.addressof(compiled.blob), self._hv.ctypes.data, self._ha.ctypes.data,
+                                   self._hn.ctypes.data, self._hf.ctypes.data)
+        if not self.h:
+            raise RuntimeError("oracle_new rejected the model blob")
+        from cosim_amd.model import CosimModel as CM
+        self.model = CM.from_address(self.L.oracle_model(self.h))   # the oracle's private (editable) copy
+        self.nq, self.nv, self.nu, self.nbody = (self.model.nq, self.model.nv, self.model.nu, self.model.nbody)
+        self._nvmax = self.L.oracle_int(self.h, b"nvmax")
+        if body_mass is not None:
+            self.set_body_mass(body_mass)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.oracle_free(self.h)
+            self.h = None
+
+    # ---- parameters
+    def set_body_mass(self, body_mass: np.ndarray):
+        """Per-env mass randomisation: masses plus the qpos0 constants that depend on them."""
+        from cosim_amd.compile import env_constants
+        from cosim_amd.model import set_field
+        body_mass = np.asarray(body_mass, dtype=np.float64)
+        c = env_constants(self.cm, body_mass[None])
+        set_field(self.model, "body_mass", body_mass)
+        set_field(self.model, "body_invweight0", c["body_invweight0"][0])
+        set_field(self.model, "dof_invweight0", c["dof_invweight0"][0])
+        set_field(self.model, "meaninertia", c["meaninertia"][0])
+
+    # ---- raw views
+    def view(self, name: str) -> np.ndarray:
+        p = self.L.oracle_ptr(self.h, name.encode())
+        if not p:
+            raise KeyError(name)
+        if name in ("M",):
+            a = np.ctypeslib.as_array(p, shape=(self._nvmax, self._nvmax))
+            return a[:self.nv, :self.nv]
+        if name == "J":
+            a = np.ctypeslib.as_array(p, shape=(self.L.oracle_int(self.h, b"maxefc"), self._nvmax))
+            return a[:self.nefc, :self.nv]
+        if name == "cdof":
+            return np.ctypeslib.as_array(p, shape=(self._nvmax, 6))[:self.nv]
+        if name == "efc_KBIP":
+            return np.ctypeslib.as_array(p, shape=(self.L.oracle_int(self.h, b"maxefc"), 4))[:self.nefc]
+        if name.startswith("efc_"):
+            return np.ctypeslib.as_array(p, shape=(self.L.oracle_int(self.h, b"maxefc"),))[:self.nefc]
+        dims = tuple(getattr(self, s) if isinstance(s, str) else s for s in _SHAPES[name])
+        return np.ctypeslib.as_array(p, shape=dims)
+
+    def __getattr__(self, name):
+        if name in ("ncon", "nefc", "ne", "nf", "nl", "solver_niter", "ls_total", "bad", "contact_overflow"):
+            return self.L.oracle_int(self.h, name.encode())
+        if name in _SHAPES or name in ("M", "J", "cdof") or name.startswith("efc_"):
+            return self.view(name)
+        raise AttributeError(name)
+
+    def contacts(self) -> np.ndarray:
+        out = np.zeros((self.ncon, 9))
+        for i in range(self.ncon):
+            self.L.oracle_contact(self.h, i, out[i].ctypes.data)
+        return out
+
+    # ---- stepping
+    def reset(self, qpos: Optional[np.ndarray] = None, qvel: Optional[np.ndarray] = None):
+        qp = None if qpos is None else np.ascontiguousarray(qpos, dtype=np.float64)
+        qv = None if qvel is None else np.ascontiguousarray(qvel, dtype=np.float64)
+        self.L.oracle_reset(self.h, None if qp is None else qp.ctypes.data, None if qv is None else qv.ctypes.data)
+
+    def forward(self):
+        self.L.oracle_forward(self.h)
+
+    def step(self):
+        self.L.oracle_step(self.h)
+
+    def control_step(self, filtered_action: np.ndarray) -> np.ndarray:
+        a = np.ascontiguousarray(filtered_action, dtype=np.float64)
+        tq = np.zeros(self.nu)
+        self.L.oracle_control_step(self.h, a.ctypes.data, tq.ctypes.data)
+        return tq
+
+    def ray_down(self, x: float, y: float, z0: float) -> float:
+        return self.L.oracle_ray_down(self.h, x, y, z0)
