@@ -1,0 +1,240 @@
+"""``BatchedEnv`` — N environment instances on one MI355X behind the reference's env API.
+
+Host-side mirror of the reference's wrapper stack for the batched case: one object plays
+``CommandWrapper(TimeLimitWrapper(StateBuildWrapper(<Robot>(config))))`` (reference
+``envs/build.py:8-24``) for ``num_envs`` instances at once.  Method names, argument meaning
+and error behaviour follow ``envs/wrappers.py``; tensors carry a leading ``[N]`` dimension and
+live on the GPU (torch is used for device memory and streams only).  All per-step arithmetic —
+command transform, delay filter, PD law, physics substeps, observation build — runs inside
+``cosim_step`` (one HIP kernel launch per control step).
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional
+
+import numpy as np
+
+from . import rng as crng
+from .compile import CompiledModel, compile_model, env_constants
+from .engine import Engine, make_obs_config
+from .model import get_field
+from .robots import ROBOTS, obs_to_dim as robot_obs_to_dim
+
+
+def _cmd_slices(stacked, non_stacked, dims, stack_size, command_dim):
+    """``StateBuildWrapper._get_cmd_index_cache`` (wrappers.py:129-158)."""
+    out = []
+    if command_dim <= 0:
+        return out
+    stacked_dim = sum(dims[n] for n in stacked)
+    off, starts = 0, []
+    for n in stacked:
+        if n == "command":
+            starts.append(off)
+        off += dims[n]
+    for k in range(stack_size):
+        for s in starts:
+            out.append(slice(k * stacked_dim + s, k * stacked_dim + s + command_dim))
+    base, off = stack_size * stacked_dim, 0
+    for n in non_stacked:
+        if n == "command":
+            out.append(slice(base + off, base + off + command_dim))
+        off += dims[n]
+    return out
+
+
+class _Data:
+    """What ``get_data()`` hands out: batched ``qpos`` / ``qvel`` views (reference: the MjData object)."""
+
+    def __init__(self, qpos, qvel):
+        self.qpos, self.qvel = qpos, qvel
+
+
+class BatchedEnv:
+    def __init__(self, config: dict, num_envs: Optional[int] = None, device: Optional[int] = None, seed: Optional[int] = None,
+                 auto_reset: bool = True, env_id0: int = 0, gain_noise: float = 0.0, compiled: Optional[CompiledModel] = None):
+        import torch  # plumbing only
+
+        eng_cfg = config.get("engine", {})
+        self.config = config
+        self.id = config["env"]["id"]
+        if self.id not in ROBOTS:
+            raise NameError(f"Please select a valid environment id. Received '{self.id}'.")
+        self.num_envs = int(num_envs if num_envs is not None else eng_cfg.get("num_envs", 1))
+        self.seed = int(seed if seed is not None else eng_cfg.get("seed", 0))
+        dev = int(device if device is not None else eng_cfg.get("device", 0))
+        if not torch.cuda.is_available():
+            raise RuntimeError("BatchedEnv needs an AMD GPU (torch.cuda.is_available() is False); there is no CPU fallback")
+        self.torch = torch
+        self.device = torch.device(f"cuda:{dev}")
+        self.env_id0 = int(env_id0)
+
+        # robot-env constructor checks (flamingo_light_v1.py:36-42)
+        level = config["random"]["precision"]
+        ptab = config["random_table"]["precision"][level]
+        self.dt_ = ptab["timestep"]
+        self.frame_skip = ptab["frame_skip"]
+        self.control_freq = 1 / (self.dt_ * self.frame_skip)
+        assert self.control_freq == 50, "Currently, only control frequency of 50 is supported."
+
+        self.cm = compiled if compiled is not None else compile_model(config)
+        blob = self.cm.blob
+        self.action_dim = blob.nu
+        self.nq, self.nv = blob.nq, blob.nv
+        self.obs_to_dim = robot_obs_to_dim(self.id, config)
+        ob = config["observation"]
+        self.command_dim = ob["command_dim"]
+        assert self.command_dim >= 0, "command_dim must be equal or greater than 0."
+        self.stack_size = int(ob["stack_size"])
+        self.stacked_obs_order = list(ob["stacked_obs_order"])
+        self.non_stacked_obs_order = list(ob["non_stacked_obs_order"])
+        self._stacked_obs_dim = sum(self.obs_to_dim[n] for n in self.stacked_obs_order)
+        self._non_stacked_obs_dim = sum(self.obs_to_dim[n] for n in self.non_stacked_obs_order)
+        self.state_dim = self.stack_size * self._stacked_obs_dim + self._non_stacked_obs_dim
+        self.cmd_slices = _cmd_slices(self.stacked_obs_order, self.non_stacked_obs_order, self.obs_to_dim,
+                                      self.stack_size, self.command_dim)
+        self.max_sim_step = int(config["env"]["max_duration"] * self.control_freq)
+        self.auto_reset = bool(auto_reset)
+
+        obs_cfg = make_obs_config(config, self.obs_to_dim, self.control_freq, self.auto_reset)
+        self.engine = Engine(self.cm, obs_cfg, self.num_envs, dev, self.seed, self.env_id0)
+        assert self.engine.query("state_dim") == self.state_dim
+        self.info_dim = self.engine.query("info_dim")
+
+        self._randomise(gain_noise)
+
+        N, t = self.num_envs, torch
+        f32 = dict(dtype=t.float32, device=self.device)
+        self.state = t.zeros((N, self.state_dim), **f32)
+        self.terminated = t.zeros((N,), dtype=t.uint8, device=self.device)
+        self.truncated = t.zeros((N,), dtype=t.uint8, device=self.device)
+        self.info_buf = t.zeros((N, self.info_dim), **f32)
+        self.user_command = t.zeros((N, max(self.command_dim, 1)), **f32)
+        self._qpos = t.zeros((N, self.nq), **f32)
+        self._qvel = t.zeros((N, self.nv), **f32)
+        self.reset_flag = False
+
+    # ------------------------------------------------------------------ domain randomisation (XMLManager step 3)
+    def _randomise(self, gain_noise: float):
+        cfg, blob, cm = self.config, self.cm.blob, self.cm
+        N, nb = self.num_envs, blob.nbody
+        gids = np.arange(self.env_id0, self.env_id0 + N, dtype=np.uint64)
+        mass = np.tile(np.array(get_field(blob, "body_mass")[:nb]), (N, 1))
+        k, load = cfg["random"]["mass_noise"], cfg["random"]["load"]
+        robot = ROBOTS[self.id]
+        for name in robot["mass_bodies"]:
+            b = cm.body_names.index(name)
+            m0 = mass[:, b].copy()
+            u = crng.uniform(self.seed, gids, 0, crng.PURPOSE_MASS, b).astype(np.float64)
+            mass[:, b] = m0 + (2.0 * u - 1.0) * m0 * k
+            if name == robot["base_body"]:
+                mass[:, b] += load
+        self.body_mass = mass
+        c = env_constants(cm, mass)
+        self.engine.set_param("body_mass", mass)
+        self.engine.set_param("body_invweight0", c["body_invweight0"][:, :, 0])
+        self.engine.set_param("dof_invweight0", c["dof_invweight0"])
+        self.engine.set_param("meaninertia", c["meaninertia"])
+        if gain_noise > 0:
+            nu = blob.nu
+            kp = np.tile(np.array(get_field(blob, "ctl_kp")[:nu]), (N, 1))
+            kd = np.tile(np.array(get_field(blob, "ctl_kd")[:nu]), (N, 1))
+            idx = np.arange(nu)[None, :]
+            up = crng.uniform(self.seed, gids[:, None], 0, crng.PURPOSE_GAIN, idx)
+            ud = crng.uniform(self.seed, gids[:, None], 1, crng.PURPOSE_GAIN, idx)
+            self.engine.set_param("kp", kp * (1.0 + gain_noise * (2.0 * up - 1.0)))
+            self.engine.set_param("kd", kd * (1.0 + gain_noise * (2.0 * ud - 1.0)))
+
+    # ------------------------------------------------------------------ BaseEnv API (wrappers.py:8-85), batched
+    def _stream(self):
+        return self.torch.cuda.current_stream(self.device).cuda_stream
+
+    def _cmd_ptr(self):
+        return self.user_command.data_ptr() if self.command_dim > 0 else None
+
+    def receive_user_command(self, user_command):
+        """Store the raw user command(s); scaling / position-mode transform happen in the next kernel launch
+        from the pre-step pose, exactly where ``CommandWrapper.receive_user_command`` reads ``get_data()``."""
+        t = self.torch
+        uc = t.as_tensor(user_command, dtype=t.float32, device=self.device)
+        if uc.ndim == 1:
+            uc = uc[None, :].expand(self.num_envs, -1)
+        if self.config["env"]["position_command"] is not False:
+            assert self.command_dim == 2, f"Currently, position command only support 2 dimenstion, but got {self.command_dim}."
+        self.user_command[:, :self.command_dim] = uc[:, :self.command_dim]
+
+    def reset(self, mask=None):
+        t = self.torch
+        mptr = None
+        if mask is not None:
+            mask = t.as_tensor(mask, device=self.device).to(t.uint8).contiguous()
+            mptr = mask.data_ptr()
+        self.engine.reset(mptr, self._cmd_ptr(), self.state.data_ptr(), self._stream())
+        self.reset_flag = True
+        return self.state, {}
+
+    def step(self, action):
+        assert self.reset_flag is True, "Call 'reset()' before calling 'step()'."
+        t = self.torch
+        a = t.as_tensor(action, dtype=t.float32, device=self.device)
+        if a.shape != (self.num_envs, self.action_dim):
+            raise ValueError(f"Action dimension mismatch. Expected {(self.num_envs, self.action_dim)}, found {tuple(a.shape)}")
+        a = a.contiguous()
+        self.engine.step(a.data_ptr(), self._cmd_ptr(), self.state.data_ptr(), self.terminated.data_ptr(),
+                         self.truncated.data_ptr(), self.info_buf.data_ptr(), self._stream())
+        if self.command_dim < 0 or self.command_dim > 6:
+            raise ValueError(f"Invalid 'command_dim': expected 0> or <7; but got {self.command_dim}.")
+        return self.state, self.terminated, self.truncated, self._info(a)
+
+    def _info(self, action) -> Dict[str, object]:
+        """Batched ``_get_info`` + ``user_command_i`` (flamingo_light_v1.py:166-183; wrappers.py:399-400)."""
+        nu, b = self.action_dim, self.info_buf
+        info = {
+            "dt": self.dt_ * self.frame_skip,
+            "action": action,
+            "action_diff_RMSE": b[:, 0],
+            "lin_vel_x": b[:, 1],
+            "lin_vel_y": b[:, 2],
+            "ang_vel_yaw": b[:, 3],
+            "torque": b[:, 4:4 + nu],
+            "set_points": b[:, 4 + nu:4 + 2 * nu],
+            "state": b[:, 4 + 2 * nu:],
+        }
+        for i in range(self.command_dim):
+            info[f"user_command_{i}"] = self.user_command[:, i]
+        return info
+
+    def event(self, event: str, value, mask=None):
+        if event == "push":
+            t = self.torch
+            v = t.as_tensor(value, dtype=t.float32, device=self.device).reshape(-1, 3)
+            if v.shape[0] == 1:
+                v = v.expand(self.num_envs, 3)
+            v = v.contiguous()
+            mptr = None
+            if mask is not None:
+                mask = t.as_tensor(mask, device=self.device).to(t.uint8).contiguous()
+                mptr = mask.data_ptr()
+            self.engine.push(v.data_ptr(), mptr, self._stream())
+        else:
+            raise NotImplementedError(f"event:{event} is not supported.")
+
+    def get_data(self):
+        self.engine.get("qpos", self._qpos.data_ptr(), self._stream())
+        self.engine.get("qvel", self._qvel.data_ptr(), self._stream())
+        return _Data(self._qpos, self._qvel)
+
+    def set_state(self, qpos=None, qvel=None, qacc_warmstart=None):
+        """Test / checkpoint hook: overwrite the physics state of all envs."""
+        t = self.torch
+        for name, v in (("qpos", qpos), ("qvel", qvel), ("qacc_warmstart", qacc_warmstart)):
+            if v is not None:
+                x = t.as_tensor(v, dtype=t.float32, device=self.device).contiguous()
+                self.engine.set(name, x.data_ptr(), self._stream())
+                t.cuda.synchronize(self.device)
+
+    def render(self):
+        pass  # headless
+
+    def close(self):
+        self.engine.close()

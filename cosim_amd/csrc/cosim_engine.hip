@@ -1,0 +1,499 @@
+// cosim_engine.hip — host side of libcosim_hip.so: the C ABI declared in include/cosim.h.
+//
+// Converts the fp64 ModelBlob into fp32 device tables, owns the per-env HBM records (state + randomised parameters),
+// and launches the one-wave-per-env kernel (cosim_kernels.hip) specialised for the model's (nv, nbody).
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "cosim_kernels.hip"
+
+using namespace cosim;
+
+static thread_local std::string g_err;
+static int fail(int code, const std::string& msg) {
+  g_err = msg;
+  return code;
+}
+#define HIP_TRY(expr)                                                                         \
+  do {                                                                                        \
+    hipError_t _e = (expr);                                                                   \
+    if (_e != hipSuccess) return fail(COSIM_EHIP, std::string(#expr) + ": " + hipGetErrorString(_e)); \
+  } while (0)
+
+struct cosim_engine {
+  int n_envs = 0, device = 0;
+  cosim_model_t model;
+  cosim_obs_config_t obs_cfg;
+  DevModel hm;  // host copies
+  DevObs ho;
+  Layout lay;
+  DevModel* d_model = nullptr;
+  DevObs* d_obs = nullptr;
+  float *d_state = nullptr, *d_params = nullptr, *d_hull_vert = nullptr, *d_hfield = nullptr, *d_dbg = nullptr;
+  int *d_hull_adr = nullptr, *d_hull_nbr = nullptr;
+  std::vector<float> h_params;
+  bool params_dirty = true;
+  uint64_t seed = 0;
+  int64_t env_id0 = 0;
+  float tol32 = 1e-6f;
+  int max_newton = 50;
+  // timing
+  bool timing = false;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  double t_accum_ms = 0.0;
+  int t_launches = 0;
+  void (*launch)(cosim_engine*, const KArgs&, int grid, hipStream_t) = nullptr;
+  int lds_bytes = 0;
+};
+
+template <int NV, int NB>
+static void launch_t(cosim_engine* e, const KArgs& a, int grid, hipStream_t s) {
+  hipLaunchKernelGGL((env_kernel<NV, NB>), dim3(grid), dim3(64), 0, s, a);
+}
+
+static int round_up(int x, int m) { return (x + m - 1) / m * m; }
+
+static int build_dev_model(cosim_engine* e) {
+  const cosim_model_t& m = e->model;
+  DevModel& d = e->hm;
+  memset(&d, 0, sizeof d);
+  d.nq = m.nq; d.nv = m.nv; d.nu = m.nu; d.nbody = m.nbody; d.njnt = m.njnt; d.ngeom = m.ngeom; d.neq = m.neq;
+  d.frame_skip = m.frame_skip; d.iterations = m.iterations; d.ls_iterations = m.ls_iterations;
+  d.ground_type = m.ground_type; d.hfield_nrow = m.hfield_nrow; d.hfield_ncol = m.hfield_ncol; d.nhullvert = m.nhullvert;
+  d.imu_body = m.imu_bodyid; d.term_mode = m.term_mode; d.nterm_body = m.nterm_body;
+  d.timestep = (float)m.timestep; d.tolerance = (float)m.tolerance; d.ls_tolerance = (float)m.ls_tolerance; d.impratio = (float)m.impratio;
+  for (int k = 0; k < 3; k++) { d.gravity[k] = (float)m.gravity[k]; d.ground_pos[k] = (float)m.ground_pos[k]; d.imu_pos[k] = (float)m.imu_pos[k]; }
+  for (int k = 0; k < 4; k++) { d.hfield_size[k] = (float)m.hfield_size[k]; d.imu_quat[k] = (float)m.imu_quat[k]; }
+  d.gyro_cutoff = (float)m.gyro_cutoff; d.vel_cutoff = (float)m.velocimeter_cutoff; d.heightmap_miss = (float)m.heightmap_miss;
+  if (m.solver != CS_SOLVER_NEWTON) return fail(COSIM_EINVAL, "only solver=\"Newton\" (the reference models' setting) is implemented");
+  if (m.ground_type != CS_GEOM_PLANE) return fail(COSIM_EINVAL, "heightfield terrain is not implemented in the HIP engine yet (flat only)");
+  if (m.npair != 0) return fail(COSIM_EINVAL, "robot self-collision pairs are not implemented in the HIP engine yet");
+  if (m.nbody > 32) return fail(COSIM_EINVAL, "nbody > 32");
+  int maxdepth = 0;
+  for (int b = 0; b < m.nbody; b++) {
+    d.body_parent[b] = m.body_parentid[b];
+    int lev = 0;
+    for (int p = b; p > 0; p = m.body_parentid[p]) lev++;
+    d.body_level[b] = lev;
+    if (lev > maxdepth) maxdepth = lev;
+    if (m.body_jntnum[b] > 1) return fail(COSIM_EINVAL, "more than one joint per body is not supported");
+    d.body_jtype[b] = m.body_jntnum[b] == 1 ? m.jnt_type[m.body_jntadr[b]] : -1;
+    d.body_qadr[b] = m.body_jntnum[b] == 1 ? m.jnt_qposadr[m.body_jntadr[b]] : 0;
+    d.body_dadr[b] = m.body_jntnum[b] == 1 ? m.jnt_dofadr[m.body_jntadr[b]] : 0;
+    int a = b;
+    while (a > 0 && m.body_dofnum[a] == 0) a = m.body_parentid[a];
+    d.body_lastdof[b] = a > 0 ? m.body_dofadr[a] + m.body_dofnum[a] - 1 : -1;
+    for (int k = 0; k < 3; k++) { d.body_pos[b][k] = (float)m.body_pos[b][k]; d.body_ipos[b][k] = (float)m.body_ipos[b][k]; d.body_inertia[b][k] = (float)m.body_inertia[b][k]; }
+    for (int k = 0; k < 4; k++) { d.body_quat[b][k] = (float)m.body_quat[b][k]; d.body_iquat[b][k] = (float)m.body_iquat[b][k]; }
+    if (m.body_jntnum[b] == 1) {
+      int j = m.body_jntadr[b];
+      for (int k = 0; k < 3; k++) { d.jnt_pos[b][k] = (float)m.jnt_pos[j][k]; d.jnt_axis[b][k] = (float)m.jnt_axis[j][k]; }
+      d.jnt_q0[b] = m.jnt_type[j] == CS_JNT_HINGE ? (float)m.qpos0[m.jnt_qposadr[j]] : 0.f;
+      d.jnt_limited[b] = m.jnt_limited[j];
+      d.jnt_margin[b] = (float)m.jnt_margin[j];
+      for (int k = 0; k < 2; k++) { d.jnt_range[b][k] = (float)m.jnt_range[j][k]; d.jnt_solref[b][k] = (float)m.jnt_solref[j][k]; }
+      for (int k = 0; k < 5; k++) d.jnt_solimp[b][k] = (float)m.jnt_solimp[j][k];
+    }
+  }
+  d.maxdepth = maxdepth;
+  for (int b = 0; b < m.nbody; b++) {
+    unsigned mask = 0;
+    for (int c = 0; c < m.nbody; c++) {
+      int a = c;
+      while (a > 0 && a != b) a = m.body_parentid[a];
+      if (a == b && (b > 0 || c == 0)) mask |= 1u << c;
+    }
+    d.body_subtree[b] = mask;
+  }
+  int nfric = 0;
+  for (int i = 0; i < m.nv; i++) {
+    d.dof_body[i] = m.dof_bodyid[i]; d.dof_parent[i] = m.dof_parentid[i];
+    d.dof_armature[i] = (float)m.dof_armature[i]; d.dof_damping[i] = (float)m.dof_damping[i];
+    for (int k = 0; k < 2; k++) d.dof_solref[i][k] = (float)m.dof_solref[i][k];
+    for (int k = 0; k < 5; k++) d.dof_solimp[i][k] = (float)m.dof_solimp[i][k];
+    int j = m.dof_jntid[i];
+    d.dof_frclimited[i] = m.jnt_type[j] == CS_JNT_HINGE ? m.jnt_actfrclimited[j] : 0;
+    d.dof_frcrange[i][0] = (float)m.jnt_actfrcrange[j][0]; d.dof_frcrange[i][1] = (float)m.jnt_actfrcrange[j][1];
+    d.dof_act[i] = -1;
+    if (m.dof_frictionloss[i] > 0) d.fric_dof[nfric++] = i;
+  }
+  d.nfric = nfric;
+  for (int g = 0; g < m.ngeom; g++) {
+    d.geom_type[g] = m.geom_type[g]; d.geom_body[g] = m.geom_bodyid[g]; d.geom_ground[g] = m.geom_ground[g];
+    d.geom_hulladr[g] = m.geom_hulladr[g]; d.geom_hullnum[g] = m.geom_hullnum[g];
+    d.geom_condim[g] = m.geom_condim[g] > m.ground_condim ? m.geom_condim[g] : m.ground_condim;
+    if (m.geom_ground[g] && d.geom_condim[g] != 3) return fail(COSIM_EINVAL, "only condim 3 contacts are implemented");
+    for (int k = 0; k < 3; k++) { d.geom_pos[g][k] = (float)m.geom_pos[g][k]; d.geom_size[g][k] = (float)m.geom_size[g][k]; d.geom_rcenter[g][k] = (float)m.geom_rcenter[g][k]; }
+    for (int k = 0; k < 4; k++) d.geom_quat[g][k] = (float)m.geom_quat[g][k];
+    d.geom_rbound[g] = (float)m.geom_rbound[g];
+    // mj_contactParam with equal priorities: solmix-weighted solref/solimp, margins by max
+    double s1 = m.ground_solmix, s2 = m.geom_solmix[g], mix;
+    if (s1 >= 1e-15 && s2 >= 1e-15) mix = s1 / (s1 + s2);
+    else if (s1 < 1e-15 && s2 < 1e-15) mix = 0.5;
+    else mix = s1 < 1e-15 ? 0.0 : 1.0;
+    for (int k = 0; k < 2; k++)
+      d.geom_solref[g][k] = (m.ground_solref[0] > 0 && m.geom_solref[g][0] > 0)
+                                ? (float)(mix * m.ground_solref[k] + (1 - mix) * m.geom_solref[g][k])
+                                : (float)fmin(m.ground_solref[k], m.geom_solref[g][k]);
+    for (int k = 0; k < 5; k++) d.geom_solimp[g][k] = (float)(mix * m.ground_solimp[k] + (1 - mix) * m.geom_solimp[g][k]);
+    double margin = fmax(m.ground_margin, m.geom_margin[g]), gap = fmax(m.ground_gap, m.geom_gap[g]);
+    d.geom_margin[g] = (float)margin;
+    d.geom_includemargin[g] = (float)(margin - gap);
+  }
+  for (int q = 0; q < m.neq; q++) {
+    d.eq_body1[q] = m.eq_body1[q]; d.eq_body2[q] = m.eq_body2[q];
+    for (int k = 0; k < 3; k++) { d.eq_anchor1[q][k] = (float)m.eq_anchor1[q][k]; d.eq_anchor2[q][k] = (float)m.eq_anchor2[q][k]; }
+    for (int k = 0; k < 2; k++) d.eq_solref[q][k] = (float)m.eq_solref[q][k];
+    for (int k = 0; k < 5; k++) d.eq_solimp[q][k] = (float)m.eq_solimp[q][k];
+  }
+  for (int u = 0; u < m.nu; u++) {
+    d.act_dof[u] = m.act_dofid[u]; d.act_ctrllimited[u] = m.act_ctrllimited[u]; d.act_gear[u] = (float)m.act_gear[u];
+    d.act_ctrlrange[u][0] = (float)m.act_ctrlrange[u][0]; d.act_ctrlrange[u][1] = (float)m.act_ctrlrange[u][1];
+    if (d.dof_act[m.act_dofid[u]] >= 0) return fail(COSIM_EINVAL, "two motors on one dof are not supported");
+    d.dof_act[m.act_dofid[u]] = u;
+    d.ctl_velmode[u] = m.ctl_velmode[u]; d.ctl_qadr[u] = m.ctl_qadr[u]; d.ctl_dadr[u] = m.ctl_dadr[u];
+    d.ctl_scale[u] = (float)m.ctl_scale[u]; d.ctl_gear[u] = (float)m.ctl_gear[u]; d.ctl_gamma[u] = (float)m.ctl_gamma[u];
+    d.ctl_maxtq[u] = (float)m.ctl_maxtq[u];
+  }
+  d.nobs_pos = m.nobs_pos; d.nobs_vel = m.nobs_vel; d.ninfo_state = m.ninfo_state; d.init_noise_nq = m.init_noise_nq;
+  for (int i = 0; i < CS_MAXOBSJ; i++) { d.obs_qadr[i] = m.obs_qadr[i]; d.obs_dadr[i] = m.obs_dadr[i]; d.obs_qgear[i] = (float)m.obs_qgear[i]; d.obs_dgear[i] = (float)m.obs_dgear[i]; }
+  for (int i = 0; i < CS_MAXINFOSTATE; i++) { d.info_kind[i] = m.info_kind[i]; d.info_adr[i] = m.info_adr[i]; d.info_gear[i] = (float)m.info_gear[i]; }
+  for (int i = 0; i < CS_MAXQ; i++) { d.init_noise_qadr[i] = m.init_noise_qadr[i]; d.init_qpos[i] = (float)m.init_qpos[i]; }
+  for (int i = 0; i < CS_MAXBODY; i++) d.term_body[i] = m.term_body[i];
+  d.ntri = m.nv * (m.nv + 1) / 2;
+  for (int r = 0, e2 = 0; r < m.nv; r++)
+    for (int c = 0; c <= r; c++, e2++) { d.tri_row[e2] = (unsigned char)r; d.tri_col[e2] = (unsigned char)c; }
+  return COSIM_OK;
+}
+
+static int build_dev_obs(cosim_engine* e) {
+  const cosim_obs_config_t& c = e->obs_cfg;
+  DevObs& o = e->ho;
+  memset(&o, 0, sizeof o);
+  if (c.stack_size < 1 || c.command_dim < 0 || c.command_dim > CS_MAXCMD) return fail(COSIM_EINVAL, "bad stack_size / command_dim");
+  if (c.n_stacked < 0 || c.n_stacked > CS_MAXFIELD || c.n_non_stacked < 0 || c.n_non_stacked > CS_MAXFIELD) return fail(COSIM_EINVAL, "bad field lists");
+  o.stack_size = c.stack_size; o.command_dim = c.command_dim; o.position_command = c.position_command;
+  o.max_sim_step = c.max_sim_step; o.auto_reset = c.auto_reset; o.noise_enabled = c.noise_enabled;
+  o.action_delay_prob = c.action_delay_prob; o.init_noise = c.init_noise;
+  for (int i = 0; i < CS_MAXCMD; i++) o.command_scales[i] = c.command_scales[i];
+  o.hm_res_x = c.hm_res_x; o.hm_res_y = c.hm_res_y; o.hm_size_x = c.hm_size_x; o.hm_size_y = c.hm_size_y;
+  for (int f = 0; f < 8; f++) { o.noise_mean[f] = c.noise_mean[f]; o.noise_std[f] = c.noise_std[f]; o.noise_lower[f] = c.noise_lower[f]; o.noise_upper[f] = c.noise_upper[f]; }
+  int el = 0;
+  for (int pass = 0; pass < 2; pass++) {
+    const int* list = pass ? c.non_stacked_field : c.stacked_field;
+    int n = pass ? c.n_non_stacked : c.n_stacked;
+    for (int i = 0; i < n; i++) {
+      int f = list[i];
+      if (f < 0 || f > 7) return fail(COSIM_EINVAL, "unknown observation field id");
+      if (f == CS_OBS_HEIGHT_MAP && c.field_dim[f] > 0) return fail(COSIM_EINVAL, "height_map observation needs heightfield terrain, which the HIP engine does not implement yet");
+      int dim = c.field_dim[f];
+      if (c.field_interval[f] < 1 && f != CS_OBS_COMMAND) return fail(COSIM_EINVAL, "observation interval must be >= 1");
+      for (int k = 0; k < dim; k++) {
+        if (el >= MAXFRAME) return fail(COSIM_EINVAL, "observation frame too large");
+        o.el_field[el] = (unsigned char)f; o.el_index[el] = (unsigned short)k;
+        o.el_interval[el] = (unsigned char)(f == CS_OBS_COMMAND ? 1 : (c.field_interval[f] > 255 ? 255 : c.field_interval[f]));
+        o.el_scale[el] = c.field_scale[f];
+        el++;
+      }
+    }
+    if (pass == 0) o.stacked_dim = el;
+  }
+  o.frame_dim = el;
+  o.non_stacked_dim = el - o.stacked_dim;
+  o.state_dim = o.stack_size * o.stacked_dim + o.non_stacked_dim;
+  o.info_dim = 4 + 2 * e->model.nu + e->model.ninfo_state;
+  return COSIM_OK;
+}
+
+static void build_layout(cosim_engine* e) {
+  const cosim_model_t& m = e->model;
+  Layout& L = e->lay;
+  int o = 0;
+  L.s_qpos = o; o += m.nq;
+  L.s_qvel = o; o += m.nv;
+  L.s_warm = o; o += m.nv;
+  L.s_delay = o; o += m.nu;
+  L.s_lastact = o; o += m.nu;
+  L.s_meta = o; o += 8;
+  L.s_cache = o; o += e->ho.frame_dim;
+  L.s_stack = o; o += e->ho.stack_size * e->ho.stacked_dim;
+  L.s_stride = round_up(o, 32);
+  int p = 0;
+  L.p_mass = p; p += m.nbody;
+  L.p_binvw = p; p += m.nbody;
+  L.p_dinvw = p; p += m.nv;
+  L.p_floss = p; p += m.nv;
+  L.p_gmu = p; p += m.ngeom;
+  L.p_kp = p; p += m.nu;
+  L.p_kd = p; p += m.nu;
+  L.p_mean = p; p += 1;
+  L.p_stride = round_up(p, 32);
+}
+
+static void default_params(cosim_engine* e) {
+  const cosim_model_t& m = e->model;
+  const Layout& L = e->lay;
+  e->h_params.assign((size_t)e->n_envs * L.p_stride, 0.f);
+  for (int n = 0; n < e->n_envs; n++) {
+    float* p = e->h_params.data() + (size_t)n * L.p_stride;
+    for (int b = 0; b < m.nbody; b++) { p[L.p_mass + b] = (float)m.body_mass[b]; p[L.p_binvw + b] = (float)m.body_invweight0[b][0]; }
+    for (int i = 0; i < m.nv; i++) { p[L.p_dinvw + i] = (float)m.dof_invweight0[i]; p[L.p_floss + i] = (float)m.dof_frictionloss[i]; }
+    for (int g = 0; g < m.ngeom; g++) p[L.p_gmu + g] = (float)fmax(1e-5, fmax(m.ground_friction[0], m.geom_friction[g][0]));
+    for (int u = 0; u < m.nu; u++) { p[L.p_kp + u] = (float)m.ctl_kp[u]; p[L.p_kd + u] = (float)m.ctl_kd[u]; }
+    p[L.p_mean] = (float)m.meaninertia;
+  }
+  e->params_dirty = true;
+}
+
+static int upload_params(cosim_engine* e) {
+  if (!e->params_dirty) return COSIM_OK;
+  HIP_TRY(hipMemcpy(e->d_params, e->h_params.data(), e->h_params.size() * sizeof(float), hipMemcpyHostToDevice));
+  e->params_dirty = false;
+  return COSIM_OK;
+}
+
+extern "C" {
+
+const char* cosim_last_error(void) { return g_err.c_str(); }
+int cosim_model_sizeof(void) { return (int)sizeof(cosim_model_t); }
+int cosim_obs_config_sizeof(void) { return (int)sizeof(cosim_obs_config_t); }
+
+int cosim_create(const cosim_model_t* model, const float* hull_vert, const int* hull_adr, const int* hull_nbr, const float* hfield,
+                 const cosim_obs_config_t* obs, int n_envs, int device, uint64_t seed, int64_t env_id0, cosim_engine_t** out) {
+  if (!model || !obs || !out || n_envs < 1) return fail(COSIM_EINVAL, "cosim_create: null argument or n_envs < 1");
+  if (model->magic != CS_MODEL_MAGIC || model->magic_end != CS_MODEL_MAGIC) return fail(COSIM_EINVAL, "cosim_create: model blob magic mismatch (layout drift?)");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail(COSIM_ENOGPU, "cosim_create: no HIP device available");
+  if (device < 0 || device >= ndev) return fail(COSIM_EINVAL, "cosim_create: bad device index");
+  HIP_TRY(hipSetDevice(device));
+  cosim_engine* e = new cosim_engine();
+  e->n_envs = n_envs; e->device = device; e->model = *model; e->obs_cfg = *obs; e->seed = seed; e->env_id0 = env_id0;
+  int rc = build_dev_model(e);
+  if (rc == COSIM_OK) rc = build_dev_obs(e);
+  if (rc != COSIM_OK) { delete e; return rc; }
+  build_layout(e);
+  const int nv = model->nv, nb = model->nbody;
+  if (nv == 18 && nb <= 14) { e->launch = launch_t<18, 14>; e->lds_bytes = (int)sizeof(EnvLds<18, 14>); }
+  else if (nv == 14 && nb <= 10) { e->launch = launch_t<14, 10>; e->lds_bytes = (int)sizeof(EnvLds<14, 10>); }
+  else if (nv == 6 && nb <= 2) { e->launch = launch_t<6, 2>; e->lds_bytes = (int)sizeof(EnvLds<6, 2>); }
+  else if (nv == 8 && nb <= 4) { e->launch = launch_t<8, 4>; e->lds_bytes = (int)sizeof(EnvLds<8, 4>); }
+  else { delete e; return fail(COSIM_EINVAL, "cosim_create: no kernel instantiation for this (nv, nbody); add one in cosim_engine.hip"); }
+  HIP_TRY(hipMalloc(&e->d_model, sizeof(DevModel)));
+  HIP_TRY(hipMalloc(&e->d_obs, sizeof(DevObs)));
+  HIP_TRY(hipMemcpy(e->d_model, &e->hm, sizeof(DevModel), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(e->d_obs, &e->ho, sizeof(DevObs), hipMemcpyHostToDevice));
+  HIP_TRY(hipMalloc(&e->d_state, (size_t)n_envs * e->lay.s_stride * sizeof(float)));
+  HIP_TRY(hipMemset(e->d_state, 0, (size_t)n_envs * e->lay.s_stride * sizeof(float)));
+  HIP_TRY(hipMalloc(&e->d_params, (size_t)n_envs * e->lay.p_stride * sizeof(float)));
+  HIP_TRY(hipMalloc(&e->d_dbg, 8192 * sizeof(float)));
+  int nhv = model->nhullvert > 0 ? model->nhullvert : 1, nhe = model->nhulledge > 0 ? model->nhulledge : 1;
+  HIP_TRY(hipMalloc(&e->d_hull_vert, (size_t)nhv * 3 * sizeof(float)));
+  HIP_TRY(hipMalloc(&e->d_hull_adr, (size_t)(nhv + 1) * sizeof(int)));
+  HIP_TRY(hipMalloc(&e->d_hull_nbr, (size_t)nhe * sizeof(int)));
+  if (model->nhullvert > 0) {
+    if (!hull_vert || !hull_adr || !hull_nbr) return fail(COSIM_EINVAL, "cosim_create: model has mesh geoms but no hull arrays were passed");
+    HIP_TRY(hipMemcpy(e->d_hull_vert, hull_vert, (size_t)model->nhullvert * 3 * sizeof(float), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(e->d_hull_adr, hull_adr, (size_t)(model->nhullvert + 1) * sizeof(int), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(e->d_hull_nbr, hull_nbr, (size_t)model->nhulledge * sizeof(int), hipMemcpyHostToDevice));
+  }
+  (void)hfield;
+  default_params(e);
+  HIP_TRY(hipEventCreate(&e->ev0));
+  HIP_TRY(hipEventCreate(&e->ev1));
+  *out = e;
+  return COSIM_OK;
+}
+
+int cosim_destroy(cosim_engine_t* e) {
+  if (!e) return COSIM_OK;
+  hipSetDevice(e->device);
+  hipFree(e->d_model); hipFree(e->d_obs); hipFree(e->d_state); hipFree(e->d_params); hipFree(e->d_dbg);
+  hipFree(e->d_hull_vert); hipFree(e->d_hull_adr); hipFree(e->d_hull_nbr);
+  if (e->ev0) hipEventDestroy(e->ev0);
+  if (e->ev1) hipEventDestroy(e->ev1);
+  delete e;
+  return COSIM_OK;
+}
+
+int cosim_query(const cosim_engine_t* e, const char* name) {
+  if (!e || !name) return fail(COSIM_EINVAL, "cosim_query: null argument");
+  std::string n(name);
+  if (n == "state_dim") return e->ho.state_dim;
+  if (n == "action_dim") return e->model.nu;
+  if (n == "command_dim") return e->ho.command_dim;
+  if (n == "info_dim") return e->ho.info_dim;
+  if (n == "nq") return e->model.nq;
+  if (n == "nv") return e->model.nv;
+  if (n == "nbody") return e->model.nbody;
+  if (n == "ngeom") return e->model.ngeom;
+  if (n == "n_envs") return e->n_envs;
+  if (n == "state_stride") return e->lay.s_stride;
+  if (n == "param_stride") return e->lay.p_stride;
+  if (n == "lds_bytes") return e->lds_bytes;
+  if (n == "stacked_dim") return e->ho.stacked_dim;
+  if (n == "frame_dim") return e->ho.frame_dim;
+  return fail(COSIM_EINVAL, "cosim_query: unknown name " + n);
+}
+
+int cosim_set_param(cosim_engine_t* e, const char* name, const float* host, int count) {
+  if (!e || !name || !host) return fail(COSIM_EINVAL, "cosim_set_param: null argument");
+  std::string n(name);
+  const cosim_model_t& m = e->model;
+  const Layout& L = e->lay;
+  int off, width;
+  if (n == "body_mass") { off = L.p_mass; width = m.nbody; }
+  else if (n == "body_invweight0") { off = L.p_binvw; width = m.nbody; }
+  else if (n == "dof_invweight0") { off = L.p_dinvw; width = m.nv; }
+  else if (n == "dof_frictionloss") { off = L.p_floss; width = m.nv; }
+  else if (n == "geom_friction") { off = L.p_gmu; width = m.ngeom; }
+  else if (n == "kp") { off = L.p_kp; width = m.nu; }
+  else if (n == "kd") { off = L.p_kd; width = m.nu; }
+  else if (n == "meaninertia") { off = L.p_mean; width = 1; }
+  else if (n == "solver_tolerance") { e->tol32 = host[0]; return COSIM_OK; }
+  else if (n == "max_newton") { e->max_newton = (int)host[0]; return COSIM_OK; }
+  else return fail(COSIM_EINVAL, "cosim_set_param: unknown parameter " + n);
+  if (count != e->n_envs * width) return fail(COSIM_EINVAL, "cosim_set_param: " + n + " expects n_envs*" + std::to_string(width) + " values");
+  for (int i = 0; i < e->n_envs; i++)
+    memcpy(e->h_params.data() + (size_t)i * L.p_stride + off, host + (size_t)i * width, width * sizeof(float));
+  e->params_dirty = true;
+  return COSIM_OK;
+}
+
+static KArgs base_args(cosim_engine* e) {
+  KArgs a;
+  memset(&a, 0, sizeof a);
+  a.dm = e->d_model; a.ob = e->d_obs; a.lay = e->lay; a.state = e->d_state; a.params = e->d_params;
+  a.hull_vert = e->d_hull_vert; a.hull_adr = e->d_hull_adr; a.hull_nbr = e->d_hull_nbr; a.hfield = e->d_hfield;
+  a.n_envs = e->n_envs; a.seed_lo = (unsigned)e->seed; a.seed_hi = (unsigned)(e->seed >> 32); a.env_id0 = e->env_id0;
+  a.tol32 = e->tol32; a.max_newton = e->max_newton;
+  return a;
+}
+
+int cosim_reset(cosim_engine_t* e, const uint8_t* mask_dev, const float* commands_dev, float* state_out_dev, void* stream) {
+  if (!e || !state_out_dev) return fail(COSIM_EINVAL, "cosim_reset: null argument");
+  HIP_TRY(hipSetDevice(e->device));
+  int rc = upload_params(e);
+  if (rc) return rc;
+  KArgs a = base_args(e);
+  a.mode = MODE_RESET; a.mask = mask_dev; a.commands = commands_dev; a.state_out = state_out_dev;
+  e->launch(e, a, e->n_envs, (hipStream_t)stream);
+  HIP_TRY(hipGetLastError());
+  return COSIM_OK;
+}
+
+int cosim_step(cosim_engine_t* e, const float* actions_dev, const float* commands_dev, float* state_out_dev, uint8_t* terminated_dev,
+               uint8_t* truncated_dev, float* info_out_dev, void* stream) {
+  if (!e || !actions_dev || !state_out_dev || !terminated_dev || !truncated_dev) return fail(COSIM_EINVAL, "cosim_step: null argument");
+  if (e->ho.command_dim > 0 && !commands_dev) return fail(COSIM_EINVAL, "cosim_step: commands_dev is required when command_dim > 0");
+  HIP_TRY(hipSetDevice(e->device));
+  int rc = upload_params(e);
+  if (rc) return rc;
+  KArgs a = base_args(e);
+  a.mode = MODE_STEP; a.actions = actions_dev; a.commands = commands_dev; a.state_out = state_out_dev;
+  a.terminated = terminated_dev; a.truncated = truncated_dev; a.info = info_out_dev;
+  hipStream_t s = (hipStream_t)stream;
+  if (e->timing) HIP_TRY(hipEventRecord(e->ev0, s));
+  e->launch(e, a, e->n_envs, s);
+  HIP_TRY(hipGetLastError());
+  if (e->timing) {
+    HIP_TRY(hipEventRecord(e->ev1, s));
+    HIP_TRY(hipEventSynchronize(e->ev1));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, e->ev0, e->ev1));
+    e->t_accum_ms += ms;
+    e->t_launches++;
+  }
+  return COSIM_OK;
+}
+
+static int locate(cosim_engine* e, const std::string& n, int* off, int* width) {
+  if (n == "qpos") { *off = e->lay.s_qpos; *width = e->model.nq; }
+  else if (n == "qvel") { *off = e->lay.s_qvel; *width = e->model.nv; }
+  else if (n == "qacc_warmstart") { *off = e->lay.s_warm; *width = e->model.nv; }
+  else return fail(COSIM_EINVAL, "unknown state field " + n);
+  return COSIM_OK;
+}
+
+int cosim_get(cosim_engine_t* e, const char* name, float* out_dev, void* stream) {
+  if (!e || !name || !out_dev) return fail(COSIM_EINVAL, "cosim_get: null argument");
+  HIP_TRY(hipSetDevice(e->device));
+  int off, width;
+  int rc = locate(e, name, &off, &width);
+  if (rc) return rc;
+  HIP_TRY(hipMemcpy2DAsync(out_dev, width * sizeof(float), e->d_state + off, e->lay.s_stride * sizeof(float), width * sizeof(float),
+                           e->n_envs, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  return COSIM_OK;
+}
+
+int cosim_set(cosim_engine_t* e, const char* name, const float* in_dev, void* stream) {
+  if (!e || !name || !in_dev) return fail(COSIM_EINVAL, "cosim_set: null argument");
+  HIP_TRY(hipSetDevice(e->device));
+  int off, width;
+  int rc = locate(e, name, &off, &width);
+  if (rc) return rc;
+  HIP_TRY(hipMemcpy2DAsync(e->d_state + off, e->lay.s_stride * sizeof(float), in_dev, width * sizeof(float), width * sizeof(float),
+                           e->n_envs, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  return COSIM_OK;
+}
+
+__global__ void push_kernel(float* state, Layout lay, const float* v, const uint8_t* mask, int n) {
+  int env = blockIdx.x * blockDim.x + threadIdx.x;
+  if (env >= n || (mask && !mask[env])) return;
+  float* rec = state + (size_t)env * lay.s_stride;
+  // qvel[:2] = (R^T v_world)[:2], qvel[2] = v_world[2]   (reference flamingo_light_v1.py:234-243; quaternion used raw)
+  float w = rec[lay.s_qpos + 3], x = rec[lay.s_qpos + 4], y = rec[lay.s_qpos + 5], z = rec[lay.s_qpos + 6];
+  float R00 = 1 - 2 * y * y - 2 * z * z, R01 = 2 * x * y - 2 * z * w, R10 = 2 * x * y + 2 * z * w, R11 = 1 - 2 * x * x - 2 * z * z,
+        R20 = 2 * x * z - 2 * y * w, R21 = 2 * y * z + 2 * x * w;
+  const float* vw = v + (size_t)env * 3;
+  rec[lay.s_qvel + 0] = R00 * vw[0] + R10 * vw[1] + R20 * vw[2];
+  rec[lay.s_qvel + 1] = R01 * vw[0] + R11 * vw[1] + R21 * vw[2];
+  rec[lay.s_qvel + 2] = vw[2];
+}
+
+int cosim_event_push(cosim_engine_t* e, const float* v_dev, const uint8_t* mask_dev, void* stream) {
+  if (!e || !v_dev) return fail(COSIM_EINVAL, "cosim_event_push: null argument");
+  HIP_TRY(hipSetDevice(e->device));
+  hipLaunchKernelGGL(push_kernel, dim3((e->n_envs + 255) / 256), dim3(256), 0, (hipStream_t)stream, e->d_state, e->lay, v_dev, mask_dev, e->n_envs);
+  HIP_TRY(hipGetLastError());
+  return COSIM_OK;
+}
+
+int cosim_debug_forward(cosim_engine_t* e, int env, const char* name, float* host_out, int capacity) {
+  if (!e || !host_out || env < 0 || env >= e->n_envs) return fail(COSIM_EINVAL, "cosim_debug_forward: bad argument");
+  (void)name;
+  HIP_TRY(hipSetDevice(e->device));
+  int rc = upload_params(e);
+  if (rc) return rc;
+  HIP_TRY(hipMemset(e->d_dbg, 0, 8192 * sizeof(float)));
+  KArgs a = base_args(e);
+  a.mode = MODE_DEBUG; a.dbg = e->d_dbg; a.dbg_env = env;
+  e->launch(e, a, 1, 0);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipDeviceSynchronize());
+  int n = capacity < 8192 ? capacity : 8192;
+  HIP_TRY(hipMemcpy(host_out, e->d_dbg, (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
+  return COSIM_OK;
+}
+
+int cosim_set_timing(cosim_engine_t* e, int enabled) {
+  if (!e) return fail(COSIM_EINVAL, "cosim_set_timing: null engine");
+  e->timing = enabled != 0;
+  e->t_accum_ms = 0.0;
+  e->t_launches = 0;
+  return COSIM_OK;
+}
+
+int cosim_kernel_time(cosim_engine_t* e, float* avg_ms, int* launches) {
+  if (!e || !avg_ms || !launches) return fail(COSIM_EINVAL, "cosim_kernel_time: null argument");
+  *launches = e->t_launches;
+  *avg_ms = e->t_launches ? (float)(e->t_accum_ms / e->t_launches) : 0.f;
+  e->t_accum_ms = 0.0;
+  e->t_launches = 0;
+  return COSIM_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,124 @@
+/* cosim.h — C ABI of the MI355X batched rollout engine (libcosim_hip.so).
+ *
+ * Drop-in boundary.  The reference is pure Python: its hot path is
+ *     env.step(action) -> StateBuildWrapper/TimeLimitWrapper/CommandWrapper -> <Robot>.step -> mj_step x frame_skip
+ * (reference envs/wrappers.py:258-269,309-320,391-405; envs/flamingo_light_v1/flamingo_light_v1.py:131-164), where
+ * the arithmetic is reached through pybind11 into libmujoco.  The entry points below are what a batched FFI for that
+ * path binds; each comment names the reference interface it replaces.  Plain pointers and sizes only, no torch types.
+ *
+ * Conventions: every function returns 0 on success or a negative COSIM_E* code (cosim_last_error() has the text);
+ * `*_dev` pointers are device (HBM) pointers owned by the caller; calls are ordered on `stream` (a hipStream_t passed
+ * as void*, NULL = default stream) and are not re-entrant per handle.
+ */
+#ifndef COSIM_H
+#define COSIM_H
+
+#include <stdint.h>
+
+#include "cosim_model.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define COSIM_OK 0
+#define COSIM_EINVAL (-1)  /* bad argument / model the engine cannot run */
+#define COSIM_EHIP (-2)    /* HIP runtime error */
+#define COSIM_ENOGPU (-3)  /* no usable device */
+
+#define CS_MAXFIELD 16
+#define CS_MAXCMD 6
+
+/* observation field ids: keys of obs_to_dim (reference flamingo_light_v1.py:68-77) */
+#define CS_OBS_DOF_POS 0
+#define CS_OBS_DOF_VEL 1
+#define CS_OBS_ANG_VEL 2
+#define CS_OBS_LIN_VEL 3
+#define CS_OBS_PROJ_GRAVITY 4
+#define CS_OBS_LAST_ACTION 5
+#define CS_OBS_HEIGHT_MAP 6
+#define CS_OBS_COMMAND 7
+
+/* The wrapper-layer configuration: what StateBuildWrapper / TimeLimitWrapper / CommandWrapper and the robot env read
+ * from config["observation"], config["env"], config["random"] (reference envs/wrappers.py:89-127,290-301,336-347;
+ * flamingo_light_v1.py:36-42,56-77). */
+typedef struct cosim_obs_config {
+  int stack_size, command_dim;
+  int n_stacked, n_non_stacked;                 /* entries used in the field lists below */
+  int stacked_field[CS_MAXFIELD], non_stacked_field[CS_MAXFIELD]; /* CS_OBS_* in config order */
+  int field_dim[8];                             /* obs_to_dim per CS_OBS_* id */
+  int field_interval[8];                        /* max(1, round(control_freq / freq)) (wrappers.py:190) */
+  float field_scale[8];                         /* config["observation"][name]["scale"] */
+  float noise_mean[8], noise_std[8], noise_lower[8], noise_upper[8]; /* random_table sensor_noise level per field */
+  int noise_enabled;                            /* 0: additive noise skipped (parity runs: level "none" == exactly 0) */
+  int position_command;                         /* config["env"]["position_command"] */
+  float command_scales[CS_MAXCMD];
+  int max_sim_step;                             /* int(max_duration * control_freq) (wrappers.py:300) */
+  float action_delay_prob, init_noise;          /* config["random"] */
+  int auto_reset;                               /* engine extension: reset an env in the step that ends its episode */
+  /* height map (config["observation"]["height_map"], reference utils/mujoco_utils.py:98-189) */
+  int hm_res_x, hm_res_y;
+  float hm_size_x, hm_size_y;
+} cosim_obs_config_t;
+
+typedef struct cosim_engine cosim_engine_t;
+
+/* Replaces build_env(config) (reference envs/build.py:8-24): compiled model + wrapper config -> N env instances on
+ * one GPU.  env_id0 is the global id of local env 0 (RNG streams are keyed by global env id, so results do not depend
+ * on how envs are sharded over GPUs).  hull_* / hfield are host pointers (copied). */
+int cosim_create(const cosim_model_t* model, const float* hull_vert, const int* hull_adr, const int* hull_nbr,
+                 const float* hfield, const cosim_obs_config_t* obs, int n_envs, int device, uint64_t seed,
+                 int64_t env_id0, cosim_engine_t** out);
+int cosim_destroy(cosim_engine_t* e);
+
+/* Sizes the caller needs to allocate buffers: "state_dim", "action_dim", "command_dim", "info_dim", "nq", "nv",
+ * "n_envs", "state_stride", "param_stride", "lds_bytes", "vgprs" ... ; returns the value or a negative error. */
+int cosim_query(const cosim_engine_t* e, const char* name);
+
+/* Per-env parameters (domain randomisation; replaces the per-construction MJCF rewrite of XMLManager.get_model_path,
+ * reference manager/xml_manager.py:43-87).  name: "body_mass"[N,nbody] "body_invweight0"[N,nbody] (translational)
+ * "dof_invweight0"[N,nv] "meaninertia"[N] "dof_frictionloss"[N,nv] "geom_friction"[N,ngeom] (sliding, already
+ * max-combined with the ground) "kp"[N,nu] "kd"[N,nu].  `host` points to host memory, float32, row-major. */
+int cosim_set_param(cosim_engine_t* e, const char* name, const float* host, int count);
+
+/* Replaces env.reset() (reference envs/wrappers.py:245-256,303-307,385-389; flamingo_light_v1.py:209-232).
+ * mask_dev: uint8[N] or NULL (= all).  commands_dev: float[N,command_dim] user commands (see cosim_step).
+ * state_out_dev: float[N,state_dim] (rows of envs that are not reset are left untouched). */
+int cosim_reset(cosim_engine_t* e, const uint8_t* mask_dev, const float* commands_dev, float* state_out_dev,
+                void* stream);
+
+/* Replaces receive_user_command() + env.step(action) (reference core/tester.py:68,90; envs/wrappers.py:349-405).
+ * actions_dev float[N,nu]; commands_dev float[N,command_dim] raw user commands (scaling / position-mode transform is
+ * applied in the kernel from the pre-step pose, as CommandWrapper.receive_user_command does before the step);
+ * state_out_dev float[N,state_dim]; terminated_dev/truncated_dev uint8[N]; info_out_dev float[N,info_dim] or NULL:
+ * [action_diff_RMSE, lin_vel_x, lin_vel_y, ang_vel_yaw, torque[nu], set_points[nu], state[k]]. */
+int cosim_step(cosim_engine_t* e, const float* actions_dev, const float* commands_dev, float* state_out_dev,
+               uint8_t* terminated_dev, uint8_t* truncated_dev, float* info_out_dev, void* stream);
+
+/* Replaces env.get_data() reads (reference flamingo_light_v1.py:247-248; wrappers.py:360-367): copies
+ * "qpos"[N,nq] / "qvel"[N,nv] / "qacc_warmstart"[N,nv] / "sim_step"[N] (as float) to a device buffer. */
+int cosim_get(cosim_engine_t* e, const char* name, float* out_dev, void* stream);
+/* Test / checkpoint hook: overwrite "qpos"/"qvel"/"qacc_warmstart" from a device buffer. */
+int cosim_set(cosim_engine_t* e, const char* name, const float* in_dev, void* stream);
+
+/* Replaces env.event("push", v) (reference flamingo_light_v1.py:234-245): v_dev float[N,3] world-frame velocity,
+ * mask_dev uint8[N] or NULL. */
+int cosim_event_push(cosim_engine_t* e, const float* v_dev, const uint8_t* mask_dev, void* stream);
+
+/* Debug hook for the parity tests: runs ONE mj_forward-equivalent on env `env` in a diagnostic kernel and copies the
+ * named intermediate to host doubles-as-float: "xpos" "xquat" "M" "cdof" "contacts" "J" "efc" "qacc" ... */
+int cosim_debug_forward(cosim_engine_t* e, int env, const char* name, float* host_out, int capacity);
+
+/* Average duration (ms) of the step kernel since the last call, measured with HIP events on the launch stream, and
+ * the number of launches averaged; resets the accumulator. */
+int cosim_kernel_time(cosim_engine_t* e, float* avg_ms, int* launches);
+int cosim_set_timing(cosim_engine_t* e, int enabled);
+
+const char* cosim_last_error(void);
+int cosim_model_sizeof(void);
+int cosim_obs_config_sizeof(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* COSIM_H */
