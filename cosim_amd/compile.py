@@ -328,9 +328,8 @@ def compile_model(config: dict, model_path: Optional[str] = None) -> CompiledMod
     m["dof_frictionloss"] = per_dof("frictionloss")
     m["dof_solref"] = np.array([joints[dof_jntid[d]]["solreffriction"] for d in range(nv)]).reshape(nv, 2)
     m["dof_solimp"] = np.array([joints[dof_jntid[d]]["solimpfriction"] for d in range(nv)]).reshape(nv, 5)
-    for d in range(nv):   # free-joint dofs carry no armature/damping/frictionloss in these models
-        if joints[dof_jntid[d]]["type"] == "free" and (m["dof_frictionloss"][d] or m["dof_armature"][d]):
-            raise ValueError("armature/frictionloss on a free joint is not supported")
+    # note: <joint type="free"> inherits class defaults (flamingo_p_v3.xml:24 gives the base joint armature 0.01 and
+    # frictionloss 0.1 on all six dofs); only the <freejoint/> shortcut ignores defaults
 
     qpos0 = np.zeros(nq)
     for ji, j in enumerate(joints):

@@ -47,6 +47,42 @@ def _p_v3(hw: dict) -> dict:
     return dict(actuators=acts)
 
 
+def _w4(hw: dict) -> dict:
+    # reference envs/w4_p_v2/w4_p_v2.py:22-45,151-187 (hips / shoulders / legs use their own max torque here)
+    sc = hw["action_scales"]
+    g, gam = hw["gear_ratio"], hw["gamma"]
+    legs = ("FL", "FR", "RL", "RR")
+    acts = []
+    for name, kp, kd, gear, gamma, mx in (("hip", hw["Kp_hip"], hw["Kd_hip"], 1.0, 1.0, hw["hip_max_torque"]),
+                                          ("shoulder", hw["Kp_shoulder"], hw["Kd_shoulder"], 1.0, 1.0, hw["shoulder_max_torque"]),
+                                          ("leg", hw["Kp_leg"], hw["Kd_leg"], g, gam, hw["leg_max_torque"])):
+        for leg in legs:
+            acts.append(dict(joint=f"{leg}_{name}_joint", vel=False, kp=kp, kd=kd, scale=sc[name], gear=gear, gamma=gamma, maxtq=mx))
+    for leg in legs:
+        acts.append(dict(joint=f"{leg}_wheel_joint", vel=True, kp=0.0, kd=hw["Kd_wheel"], scale=sc["wheel"], gear=1.0,
+                         gamma=1.0, maxtq=hw["wheel_max_torque"]))
+    return dict(actuators=acts)
+
+
+_HUMANOID_GROUPS = ["hip_pitch", "torso", "hip_roll", "shoulder_pitch", "hip_yaw", "shoulder_roll", "knee", "shoulder_yaw",
+                    "ankle_pitch", "elbow_pitch", "ankle_roll", "elbow_yaw"]
+
+
+def _humanoid_joints():
+    # joint_names_in_order (reference envs/humanoid_p_v0/humanoid_p_v0.py:139-150) == XML actuator order (:157-179)
+    out = []
+    for g in _HUMANOID_GROUPS:
+        out += [("torso_joint", g)] if g == "torso" else [(f"left_{g}_joint", g), (f"right_{g}_joint", g)]
+    return out
+
+
+def _humanoid(hw: dict) -> dict:
+    # reference envs/humanoid_p_v0/humanoid_p_v0.py:22-90,186-250
+    sc = hw["action_scales"]
+    return dict(actuators=[dict(joint=j, vel=False, kp=hw[f"Kp_{g}"], kd=hw[f"Kd_{g}"], scale=sc[g], gear=1.0, gamma=1.0,
+                                maxtq=hw[f"{g}_joint_max_torque"]) for j, g in _humanoid_joints()])
+
+
 ROBOTS: Dict[str, dict] = {
     "flamingo_light_v1": dict(
         xml="flamingo_light_v1.xml",
@@ -86,6 +122,48 @@ ROBOTS: Dict[str, dict] = {
                      "left_leg_link", "right_leg_link", "left_wheel_link", "right_wheel_link"],
         friction_bodies=["left_wheel_link", "right_wheel_link"],
         heightmap_miss=1.0,
+    ),
+    "w4_p_v2": dict(
+        xml="w4_p_v2.xml",
+        base_body="base_link",
+        control=_w4,
+        # _get_obs (w4_p_v2.py:104-120): hips, shoulders, legs (geared) ; dof_vel adds the wheels
+        obs_pos=[(f"{l}_{n}_joint", "gear" if n == "leg" else 1.0) for n in ("hip", "shoulder", "leg") for l in ("FL", "FR", "RL", "RR")],
+        obs_vel=[(f"{l}_{n}_joint", "gear" if n == "leg" else 1.0) for n in ("hip", "shoulder", "leg") for l in ("FL", "FR", "RL", "RR")]
+        + [(f"{l}_wheel_joint", 1.0) for l in ("FL", "FR", "RL", "RR")],
+        info_state=[("pos", i) for i in range(12)] + [("vel", i) for i in range(12, 16)],   # ungeared (:204-206)
+        info_state_geared=False,
+        init_height=0.47957,  # :246
+        init_noise_joints="all_hinge",
+        term_mode=0, term_bodies=[],  # _is_done returns False (:225-226)
+        mass_bodies=["base_link", "FL_hip_link", "FR_hip_link", "RL_hip_link", "RR_hip_link", "FL_shoulder_link", "FR_shoulder_link",
+                     "RL_shoulder_link", "RR_shoulder_link", "FL_leg_link", "FR_leg_link", "RL_leg_link", "RR_leg_link",
+                     "FL_wheel_link", "FR_wheel_link", "RL_wheel_link", "RR_wheel_link"],
+        friction_bodies=["FL_wheel_link", "FR_wheel_link", "RL_wheel_link", "RR_wheel_link"],
+        heightmap_miss=1.0,
+    ),
+    "humanoid_p_v0": dict(
+        xml="humanoid_p_v0.xml",
+        base_body="pelvis_link",
+        control=_humanoid,
+        obs_pos=[(j, 1.0) for j, _ in _humanoid_joints()],
+        obs_vel=[(j, 1.0) for j, _ in _humanoid_joints()],
+        info_state=[("pos", i) for i in range(23)],   # joint_state = dof_pos (:268)
+        info_state_geared=False,
+        init_height=1.105,  # :308
+        init_noise_joints="all_hinge",
+        term_mode=0, term_bodies=[],
+        mass_bodies=["pelvis_link", "torso_link",
+                     "left_shoulder_pitch_link", "left_shoulder_roll_link", "left_shoulder_yaw_link",
+                     "left_elbow_pitch_link", "left_elbow_yaw_link",
+                     "right_shoulder_pitch_link", "right_shoulder_roll_link", "right_shoulder_yaw_link",
+                     "right_elbow_pitch_link", "right_elbow_yaw_link",
+                     "left_hip_pitch_link", "left_hip_roll_link", "left_hip_yaw_link",
+                     "left_knee_link", "left_ankle_pitch_link", "left_ankle_roll_link",
+                     "right_hip_pitch_link", "right_hip_roll_link", "right_hip_yaw_link",
+                     "right_knee_link", "right_ankle_pitch_link", "right_ankle_roll_link"],
+        friction_bodies=["left_ankle_roll_link", "right_ankle_roll_link"],
+        heightmap_miss=5.0,   # z_min_world = -5.0 (envs/humanoid_p_v0/utils/mujoco_utils.py:141)
     ),
 }
 

@@ -1,0 +1,144 @@
+"""Host-side logic that needs no GPU: config builder, model compiler, RNG, ABI surface, error behaviour."""
+import ctypes
+import json
+import os
+
+import numpy as np
+import pytest
+
+from cosim_amd import rng as crng
+from cosim_amd.batched_env import _cmd_slices
+from cosim_amd.compile import compile_model, env_constants
+from cosim_amd.config import PARITY_RANDOM, make_config
+from cosim_amd.engine import EXPORTS, ObsConfig, load_library, make_obs_config
+from cosim_amd.model import CosimModel, get_field
+from cosim_amd.robots import ROBOTS, obs_to_dim
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+
+
+def test_philox_known_answer_vectors():
+    # Random123 known-answer tests for philox4x32-10
+    z = np.uint32(0)
+    out = crng.philox4x32(z, z, z, z, z, z)
+    assert [int(x) for x in out] == [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]
+    f = np.uint32(0xFFFFFFFF)
+    out = crng.philox4x32(f, f, f, f, f, f)
+    assert [int(x) for x in out] == [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]
+    u = crng.uniform(7, np.arange(1000), 3, crng.PURPOSE_DELAY, 0)
+    assert u.min() > 0 and u.max() < 1 and abs(u.mean() - 0.5) < 0.05
+
+
+def test_config_matches_gui_defaults():
+    cfg = make_config("flamingo_light_v1")
+    assert cfg["random"] == dict(precision="medium", sensor_noise="low", init_noise=0.05, sliding_friction=0.8,
+                                 torsional_friction=0.02, rolling_friction=0.01, friction_loss=0.1, action_delay_prob=0.05,
+                                 mass_noise=0.05, load=0.0)
+    ob = cfg["observation"]
+    assert ob["stacked_obs_order"] == ["dof_pos", "dof_vel", "ang_vel", "projected_gravity", "last_action"]
+    assert ob["dof_vel"] == {"freq": 50, "scale": 0.15} and ob["last_action"] == {"freq": 50, "scale": 1.0}
+    assert ob["height_map"] is None and ob["lin_vel_x"] is None
+    assert ob["command_scales"] == {"0": 2.0, "1": 1.0, "2": 0.25, "3": 1.0}
+    assert cfg["hardware"]["Kp_shoulder"] == 15.0 and cfg["hardware"]["action_scales"]["wheel"] == 40.0
+    with pytest.raises(NameError):
+        make_config("no_such_robot")
+
+
+def test_state_dims_and_cmd_slices_match_reference(golden_dir):
+    meta = json.load(open(os.path.join(golden_dir, "wrappers_meta.json")))
+    for env_id in ROBOTS:
+        cfg = make_config(env_id)
+        dims = obs_to_dim(env_id, cfg)
+        ob = cfg["observation"]
+        sd = sum(dims[n] for n in ob["stacked_obs_order"]) * ob["stack_size"] + sum(dims[n] for n in ob["non_stacked_obs_order"])
+        assert sd == meta[f"{env_id}_default"]["state_dim"]
+        sl = _cmd_slices(ob["stacked_obs_order"], ob["non_stacked_obs_order"], dims, ob["stack_size"], ob["command_dim"])
+        assert [[s.start, s.stop] for s in sl] == meta[f"{env_id}_default"]["cmd_slices"]
+
+
+def test_compiled_model_facts_light_v1():
+    cm = compile_model(make_config("flamingo_light_v1", random=PARITY_RANDOM))
+    b = cm.blob
+    assert (b.nq, b.nv, b.nu, b.nbody, b.neq, b.npair) == (19, 18, 4, 14, 2, 0)
+    assert np.array(get_field(b, "body_mass")[:14]).sum() == pytest.approx(4.94905, abs=1e-5)
+    assert list(get_field(b, "ctl_qadr")[:4]) == [7, 10, 9, 12]                        # sh 7,10; wheel 9,12
+    assert b.timestep == 0.005 and b.frame_skip == 4 and b.iterations == 50
+    assert np.allclose(get_field(b, "ground_friction"), [0.8, 0.02, 0.01])
+    # connect anchors coincide at qpos0
+    from cosim_amd.compile import forward_kinematics
+    fk = forward_kinematics(cm.const["m"], np.array(get_field(b, "qpos0")[:19]))
+    for e in range(2):
+        b1, b2 = get_field(b, "eq_body1")[e], get_field(b, "eq_body2")[e]
+        p1 = fk["xpos"][b1] + fk["xmat"][b1] @ get_field(b, "eq_anchor1")[e]
+        p2 = fk["xpos"][b2] + fk["xmat"][b2] @ get_field(b, "eq_anchor2")[e]
+        np.testing.assert_allclose(p1, p2, atol=1e-12)
+    # frictionloss default classes joints / wheels were rewritten to friction_loss, casters stay at 0
+    fl = np.array(get_field(b, "dof_frictionloss")[:18])
+    assert np.allclose(fl[6:14], 0.1) and np.allclose(fl[14:], 0.0) and np.allclose(fl[:6], 0.0)
+
+
+@pytest.mark.parametrize("env_id", ["flamingo_light_v1", "flamingo_p_v3"])
+def test_env_constants_batched_equals_single(env_id):
+    cm = compile_model(make_config(env_id, random=PARITY_RANDOM))
+    nb = cm.blob.nbody
+    m0 = np.array(get_field(cm.blob, "body_mass")[:nb])
+    rng = np.random.default_rng(0)
+    masses = m0[None] * (1 + 0.05 * rng.uniform(-1, 1, size=(5, nb)))
+    c = env_constants(cm, masses)
+    for i in range(5):
+        ci = env_constants(cm, masses[i][None])
+        for k in c:
+            np.testing.assert_allclose(c[k][i], ci[k][0], rtol=1e-12)
+    nominal = env_constants(cm, m0[None])
+    np.testing.assert_allclose(nominal["dof_invweight0"][0], np.array(get_field(cm.blob, "dof_invweight0")[:cm.blob.nv]))
+    assert nominal["meaninertia"][0] == pytest.approx(cm.blob.meaninertia)
+
+
+def test_obs_config_errors_follow_reference():
+    cfg = make_config("flamingo_light_v1")
+    dims = obs_to_dim("flamingo_light_v1", cfg)
+    c = make_obs_config(cfg, dims, 50.0, True)
+    assert (c.stack_size, c.command_dim, c.n_stacked, c.n_non_stacked, c.max_sim_step) == (3, 4, 5, 1, 6000)
+    assert list(c.field_interval)[:6] == [1, 1, 1, 1, 1, 1] and c.noise_enabled == 1
+    bad = make_config("flamingo_light_v1")
+    bad["observation"]["dof_vel"]["freq"] = 0
+    with pytest.raises(ValueError):            # wrappers.py:186-187
+        make_obs_config(bad, dims, 50.0, True)
+    bad = make_config("flamingo_light_v1")
+    bad["observation"]["stacked_obs_order"] = ["lin_vel_x"]     # offered by the GUI, provided by no env
+    with pytest.raises(KeyError):              # wrappers.py:116
+        make_obs_config(bad, dims, 50.0, True)
+    slow = make_config("flamingo_light_v1")
+    slow["observation"]["dof_vel"]["freq"] = 10
+    assert make_obs_config(slow, dims, 50.0, True).field_interval[1] == 5
+
+
+def test_abi_library_exports_and_layouts():
+    L = load_library()
+    for sym in EXPORTS:
+        assert hasattr(L, sym), sym
+    assert L.cosim_model_sizeof() == ctypes.sizeof(CosimModel)
+    assert L.cosim_obs_config_sizeof() == ctypes.sizeof(ObsConfig)
+    # every entry point declared in include/cosim.h is exported
+    import re
+    hdr = open(os.path.join(ROOT, "include", "cosim.h")).read()
+    declared = set(re.findall(r"\b(cosim_[a-z_]+)\s*\(", hdr))
+    assert declared <= set(EXPORTS) | {"cosim_engine"}, declared - set(EXPORTS)
+    for sym in declared:
+        assert hasattr(L, sym), sym
+
+
+def test_engine_fails_loudly_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from cosim_amd.build import build_env
+    with pytest.raises(RuntimeError):
+        build_env(make_config("flamingo_light_v1"))
+    with pytest.raises(NameError):
+        build_env({"env": {"id": "nope"}})
+
+
+def test_oracle_and_engine_share_the_model_layout():
+    from oracle.oracle import lib
+    assert lib().oracle_model_sizeof() == ctypes.sizeof(CosimModel)
