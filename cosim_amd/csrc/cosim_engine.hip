@@ -43,7 +43,8 @@ struct cosim_engine {
   int max_newton = 50;
   // timing
   bool timing = false;
-  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  std::vector<hipEvent_t> ev;  // event pairs (start, stop) of timed launches not yet read back
+  int ev_used = 0;
   double t_accum_ms = 0.0;
   int t_launches = 0;
   void (*launch)(cosim_engine*, const KArgs&, int grid, hipStream_t) = nullptr;
@@ -302,8 +303,6 @@ int cosim_create(const cosim_model_t* model, const float* hull_vert, const int* 
   }
   (void)hfield;
   default_params(e);
-  HIP_TRY(hipEventCreate(&e->ev0));
-  HIP_TRY(hipEventCreate(&e->ev1));
   *out = e;
   return COSIM_OK;
 }
@@ -313,8 +312,7 @@ int cosim_destroy(cosim_engine_t* e) {
   hipSetDevice(e->device);
   hipFree(e->d_model); hipFree(e->d_obs); hipFree(e->d_state); hipFree(e->d_params); hipFree(e->d_dbg);
   hipFree(e->d_hull_vert); hipFree(e->d_hull_adr); hipFree(e->d_hull_nbr);
-  if (e->ev0) hipEventDestroy(e->ev0);
-  if (e->ev1) hipEventDestroy(e->ev1);
+  for (hipEvent_t x : e->ev) hipEventDestroy(x);
   delete e;
   return COSIM_OK;
 }
@@ -363,6 +361,18 @@ int cosim_set_param(cosim_engine_t* e, const char* name, const float* host, int 
   return COSIM_OK;
 }
 
+static int drain_events(cosim_engine* e) {
+  for (int i = 0; i + 1 < e->ev_used; i += 2) {
+    HIP_TRY(hipEventSynchronize(e->ev[i + 1]));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, e->ev[i], e->ev[i + 1]));
+    e->t_accum_ms += ms;
+    e->t_launches++;
+  }
+  e->ev_used = 0;
+  return COSIM_OK;
+}
+
 static KArgs base_args(cosim_engine* e) {
   KArgs a;
   memset(&a, 0, sizeof a);
@@ -396,17 +406,20 @@ int cosim_step(cosim_engine_t* e, const float* actions_dev, const float* command
   a.mode = MODE_STEP; a.actions = actions_dev; a.commands = commands_dev; a.state_out = state_out_dev;
   a.terminated = terminated_dev; a.truncated = truncated_dev; a.info = info_out_dev;
   hipStream_t s = (hipStream_t)stream;
-  if (e->timing) HIP_TRY(hipEventRecord(e->ev0, s));
+  // kernel timing: one HIP event pair per launch on the launch stream, read back in cosim_kernel_time() (no sync here)
+  int slot = -1;
+  if (e->timing) {
+    if (e->ev_used + 2 > (int)e->ev.size()) {
+      if (e->ev.size() >= 16384) { int rc2 = drain_events(e); if (rc2) return rc2; }
+      else for (int i = 0; i < 2; i++) { hipEvent_t x; HIP_TRY(hipEventCreate(&x)); e->ev.push_back(x); }
+    }
+    slot = e->ev_used;
+    e->ev_used += 2;
+    HIP_TRY(hipEventRecord(e->ev[slot], s));
+  }
   e->launch(e, a, e->n_envs, s);
   HIP_TRY(hipGetLastError());
-  if (e->timing) {
-    HIP_TRY(hipEventRecord(e->ev1, s));
-    HIP_TRY(hipEventSynchronize(e->ev1));
-    float ms = 0.f;
-    HIP_TRY(hipEventElapsedTime(&ms, e->ev0, e->ev1));
-    e->t_accum_ms += ms;
-    e->t_launches++;
-  }
+  if (slot >= 0) HIP_TRY(hipEventRecord(e->ev[slot + 1], s));
   return COSIM_OK;
 }
 
@@ -481,6 +494,9 @@ int cosim_debug_forward(cosim_engine_t* e, int env, const char* name, float* hos
 
 int cosim_set_timing(cosim_engine_t* e, int enabled) {
   if (!e) return fail(COSIM_EINVAL, "cosim_set_timing: null engine");
+  HIP_TRY(hipSetDevice(e->device));
+  int rc = drain_events(e);
+  if (rc) return rc;
   e->timing = enabled != 0;
   e->t_accum_ms = 0.0;
   e->t_launches = 0;
@@ -489,6 +505,9 @@ int cosim_set_timing(cosim_engine_t* e, int enabled) {
 
 int cosim_kernel_time(cosim_engine_t* e, float* avg_ms, int* launches) {
   if (!e || !avg_ms || !launches) return fail(COSIM_EINVAL, "cosim_kernel_time: null argument");
+  HIP_TRY(hipSetDevice(e->device));
+  int rc = drain_events(e);
+  if (rc) return rc;
   *launches = e->t_launches;
   *avg_ms = e->t_launches ? (float)(e->t_accum_ms / e->t_launches) : 0.f;
   e->t_accum_ms = 0.0;

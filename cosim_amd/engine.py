@@ -67,6 +67,9 @@ def load_library():
     global _lib
     if _lib is not None:
         return _lib
+    # torch first: libcosim_hip.so must bind to the HIP runtime torch has loaded (torch ships its own libamdhip64);
+    # two HIP runtimes in one process do not see each other's devices, streams or allocations.
+    import torch  # noqa: F401
     if not os.path.isfile(LIB_PATH):
         raise RuntimeError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                            "(the HIP engine has no CPU fallback)")
