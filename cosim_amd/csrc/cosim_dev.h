@@ -20,47 +20,50 @@ constexpr int MAXROW = 64;        // constraint rows per env == lanes per wave
 constexpr int MAXFRAME = 256;     // single-frame observation elements (stacked + non-stacked)
 constexpr int MAXTRI = MAXD * (MAXD + 1) / 2;
 
-// fp32 device copy of the ModelBlob plus derived tables
+// fp32 device copy of the ModelBlob.  Everything a lane needs about "its" body / dof / geom / actuator / table row sits
+// in ONE 512-byte record per lane index, so every model read is <record base> + <immediate offset>: no per-array
+// address registers (a flat struct of arrays cost ~100 VGPRs of hoisted 64-bit addresses and spilled to scratch).
+struct LaneRec {
+  // ---- body (index = body id); one joint per body at most
+  int b_parent, b_level, b_jtype /* -1 none, 0 free, 3 hinge */, b_qadr, b_dadr, b_lastdof;
+  unsigned b_subtree;  // bit c: body c is in this body's subtree (incl. itself)
+  unsigned b_dofmask;  // bit d: dof d is on the chain from the root to this body
+  float b_pos[3], b_quat[4], b_ipos[3], b_iquat[4], b_inertia[3], j_pos[3], j_axis[3], j_q0;
+  int j_limited;
+  float j_range[2], j_margin, j_solref[2], j_solimp[5];
+  // ---- dof (index = dof id)
+  int d_body, d_parent, d_frclimited, d_act, d_fric /* i-th dof that carries a frictionloss row */;
+  unsigned d_ancmask;  // ancestors of this dof incl. itself
+  float d_armature, d_damping, d_solref[2], d_solimp[5], d_frcrange[2];
+  // ---- robot collision geom (index = geom id); contact parameters already mixed with the ground's
+  int g_type, g_body, g_ground, g_hulladr, g_hullnum;
+  float g_pos[3], g_quat[4], g_size[3], g_rbound, g_rcenter[3], g_solref[2], g_solimp[5], g_margin, g_incmargin;
+  // ---- actuator + robot-env control law (index = actuator id)
+  int a_dof, a_ctrllimited, a_velmode, a_qadr, a_dadr;
+  float a_gear, a_ctrlrange[2], a_scale, a_cgear, a_gamma, a_maxtq;
+  // ---- observation / info / reset tables (index = table row)
+  int o_qadr, o_dadr, i_kind, i_adr, n_qadr, t_body;
+  float o_qgear, o_dgear, i_gear, init_qpos;
+  // ---- equality connect (index = equality id)
+  int e_body1, e_body2;
+  float e_anchor1[3], e_anchor2[3], e_solref[2], e_solimp[5];
+  int pad[3];
+};
+static_assert(sizeof(LaneRec) == 512, "LaneRec must stay 512 bytes (immediate-offset addressing)");
+
 struct DevModel {
   int nq, nv, nu, nbody, njnt, ngeom, neq, nfric;
   int frame_skip, iterations, ls_iterations, maxdepth;
   int ground_type, hfield_nrow, hfield_ncol, nhullvert;
   int imu_body, term_mode, nterm_body, ntri;
+  int nobs_pos, nobs_vel, ninfo_state, init_noise_nq;
+  unsigned imu_dofmask;
   float timestep, tolerance, ls_tolerance, impratio;
   float gravity[3];
   float ground_pos[3];
   float hfield_size[4];
   float imu_pos[3], imu_quat[4], gyro_cutoff, vel_cutoff, heightmap_miss;
-  // bodies (one joint per body at most)
-  int body_parent[MAXB], body_level[MAXB], body_jtype[MAXB] /* -1 none, 0 free, 3 hinge */, body_qadr[MAXB], body_dadr[MAXB];
-  int body_lastdof[MAXB];      // last dof of the body or of its nearest ancestor with dofs (-1: none)
-  unsigned body_subtree[MAXB]; // bit c set: body c is in the subtree of this body (incl. itself)
-  float body_pos[MAXB][3], body_quat[MAXB][4], body_ipos[MAXB][3], body_iquat[MAXB][4], body_inertia[MAXB][3];
-  float jnt_pos[MAXB][3], jnt_axis[MAXB][3], jnt_q0[MAXB];
-  int jnt_limited[MAXB];
-  float jnt_range[MAXB][2], jnt_margin[MAXB], jnt_solref[MAXB][2], jnt_solimp[MAXB][5];
-  // dofs
-  int dof_body[MAXD], dof_parent[MAXD], dof_frclimited[MAXD];
-  float dof_armature[MAXD], dof_damping[MAXD], dof_solref[MAXD][2], dof_solimp[MAXD][5], dof_frcrange[MAXD][2];
-  int dof_act[MAXD];  // actuator driving this dof (-1: none)
-  int fric_dof[MAXD]; // dofs that carry a frictionloss row in the model (nfric entries)
-  // robot collision geoms against the ground (contact parameters already mixed with the ground's)
-  int geom_type[MAXG], geom_body[MAXG], geom_ground[MAXG], geom_hulladr[MAXG], geom_hullnum[MAXG], geom_condim[MAXG];
-  float geom_pos[MAXG][3], geom_quat[MAXG][4], geom_size[MAXG][3], geom_rbound[MAXG], geom_rcenter[MAXG][3];
-  float geom_solref[MAXG][2], geom_solimp[MAXG][5], geom_margin[MAXG], geom_includemargin[MAXG];
-  // equality connect
-  int eq_body1[MAXEQ], eq_body2[MAXEQ];
-  float eq_anchor1[MAXEQ][3], eq_anchor2[MAXEQ][3], eq_solref[MAXEQ][2], eq_solimp[MAXEQ][5];
-  // actuators + robot-env control law
-  int act_dof[MAXU], act_ctrllimited[MAXU], ctl_velmode[MAXU], ctl_qadr[MAXU], ctl_dadr[MAXU];
-  float act_gear[MAXU], act_ctrlrange[MAXU][2];
-  float ctl_scale[MAXU], ctl_gear[MAXU], ctl_gamma[MAXU], ctl_maxtq[MAXU];
-  // robot-env observation / info / reset tables
-  int nobs_pos, nobs_vel, ninfo_state, init_noise_nq;
-  int obs_qadr[CS_MAXOBSJ], obs_dadr[CS_MAXOBSJ], info_kind[CS_MAXINFOSTATE], info_adr[CS_MAXINFOSTATE];
-  int init_noise_qadr[CS_MAXQ];
-  float obs_qgear[CS_MAXOBSJ], obs_dgear[CS_MAXOBSJ], info_gear[CS_MAXINFOSTATE], init_qpos[CS_MAXQ];
-  int term_body[MAXB];
+  LaneRec rec[64];
   // packed lower-triangle index -> (row, col)
   unsigned char tri_row[MAXTRI], tri_col[MAXTRI];
 };

@@ -73,98 +73,107 @@ static int build_dev_model(cosim_engine* e) {
   if (m.solver != CS_SOLVER_NEWTON) return fail(COSIM_EINVAL, "only solver=\"Newton\" (the reference models' setting) is implemented");
   if (m.ground_type != CS_GEOM_PLANE) return fail(COSIM_EINVAL, "heightfield terrain is not implemented in the HIP engine yet (flat only)");
   if (m.npair != 0) return fail(COSIM_EINVAL, "robot self-collision pairs are not implemented in the HIP engine yet");
-  if (m.nbody > 32) return fail(COSIM_EINVAL, "nbody > 32");
+  if (m.nbody > 32 || m.nv > 32 || m.ngeom > 32 || m.nq > 64) return fail(COSIM_EINVAL, "model exceeds the per-lane record capacity");
+  if (m.neq > MAXEQ) return fail(COSIM_EINVAL, "too many equalities");
   int maxdepth = 0;
+  // dof ancestor masks
+  unsigned anc[MAXD];
+  for (int i = 0; i < m.nv; i++) anc[i] = (1u << i) | (m.dof_parentid[i] >= 0 ? anc[m.dof_parentid[i]] : 0u);
   for (int b = 0; b < m.nbody; b++) {
-    d.body_parent[b] = m.body_parentid[b];
+    LaneRec& r = d.rec[b];
+    r.b_parent = m.body_parentid[b];
     int lev = 0;
     for (int p = b; p > 0; p = m.body_parentid[p]) lev++;
-    d.body_level[b] = lev;
+    r.b_level = lev;
     if (lev > maxdepth) maxdepth = lev;
     if (m.body_jntnum[b] > 1) return fail(COSIM_EINVAL, "more than one joint per body is not supported");
-    d.body_jtype[b] = m.body_jntnum[b] == 1 ? m.jnt_type[m.body_jntadr[b]] : -1;
-    d.body_qadr[b] = m.body_jntnum[b] == 1 ? m.jnt_qposadr[m.body_jntadr[b]] : 0;
-    d.body_dadr[b] = m.body_jntnum[b] == 1 ? m.jnt_dofadr[m.body_jntadr[b]] : 0;
+    r.b_jtype = m.body_jntnum[b] == 1 ? m.jnt_type[m.body_jntadr[b]] : -1;
+    r.b_qadr = m.body_jntnum[b] == 1 ? m.jnt_qposadr[m.body_jntadr[b]] : 0;
+    r.b_dadr = m.body_jntnum[b] == 1 ? m.jnt_dofadr[m.body_jntadr[b]] : 0;
     int a = b;
     while (a > 0 && m.body_dofnum[a] == 0) a = m.body_parentid[a];
-    d.body_lastdof[b] = a > 0 ? m.body_dofadr[a] + m.body_dofnum[a] - 1 : -1;
-    for (int k = 0; k < 3; k++) { d.body_pos[b][k] = (float)m.body_pos[b][k]; d.body_ipos[b][k] = (float)m.body_ipos[b][k]; d.body_inertia[b][k] = (float)m.body_inertia[b][k]; }
-    for (int k = 0; k < 4; k++) { d.body_quat[b][k] = (float)m.body_quat[b][k]; d.body_iquat[b][k] = (float)m.body_iquat[b][k]; }
+    r.b_lastdof = a > 0 ? m.body_dofadr[a] + m.body_dofnum[a] - 1 : -1;
+    r.b_dofmask = r.b_lastdof >= 0 ? anc[r.b_lastdof] : 0u;
+    unsigned mask = 0;
+    for (int c = 0; c < m.nbody; c++) {
+      int q = c;
+      while (q > 0 && q != b) q = m.body_parentid[q];
+      if (q == b && (b > 0 || c == 0)) mask |= 1u << c;
+    }
+    r.b_subtree = mask;
+    for (int k = 0; k < 3; k++) { r.b_pos[k] = (float)m.body_pos[b][k]; r.b_ipos[k] = (float)m.body_ipos[b][k]; r.b_inertia[k] = (float)m.body_inertia[b][k]; }
+    for (int k = 0; k < 4; k++) { r.b_quat[k] = (float)m.body_quat[b][k]; r.b_iquat[k] = (float)m.body_iquat[b][k]; }
     if (m.body_jntnum[b] == 1) {
       int j = m.body_jntadr[b];
-      for (int k = 0; k < 3; k++) { d.jnt_pos[b][k] = (float)m.jnt_pos[j][k]; d.jnt_axis[b][k] = (float)m.jnt_axis[j][k]; }
-      d.jnt_q0[b] = m.jnt_type[j] == CS_JNT_HINGE ? (float)m.qpos0[m.jnt_qposadr[j]] : 0.f;
-      d.jnt_limited[b] = m.jnt_limited[j];
-      d.jnt_margin[b] = (float)m.jnt_margin[j];
-      for (int k = 0; k < 2; k++) { d.jnt_range[b][k] = (float)m.jnt_range[j][k]; d.jnt_solref[b][k] = (float)m.jnt_solref[j][k]; }
-      for (int k = 0; k < 5; k++) d.jnt_solimp[b][k] = (float)m.jnt_solimp[j][k];
+      for (int k = 0; k < 3; k++) { r.j_pos[k] = (float)m.jnt_pos[j][k]; r.j_axis[k] = (float)m.jnt_axis[j][k]; }
+      r.j_q0 = m.jnt_type[j] == CS_JNT_HINGE ? (float)m.qpos0[m.jnt_qposadr[j]] : 0.f;
+      r.j_limited = m.jnt_limited[j];
+      r.j_margin = (float)m.jnt_margin[j];
+      for (int k = 0; k < 2; k++) { r.j_range[k] = (float)m.jnt_range[j][k]; r.j_solref[k] = (float)m.jnt_solref[j][k]; }
+      for (int k = 0; k < 5; k++) r.j_solimp[k] = (float)m.jnt_solimp[j][k];
     }
   }
   d.maxdepth = maxdepth;
-  for (int b = 0; b < m.nbody; b++) {
-    unsigned mask = 0;
-    for (int c = 0; c < m.nbody; c++) {
-      int a = c;
-      while (a > 0 && a != b) a = m.body_parentid[a];
-      if (a == b && (b > 0 || c == 0)) mask |= 1u << c;
-    }
-    d.body_subtree[b] = mask;
-  }
+  d.imu_dofmask = d.rec[m.imu_bodyid].b_dofmask;
   int nfric = 0;
   for (int i = 0; i < m.nv; i++) {
-    d.dof_body[i] = m.dof_bodyid[i]; d.dof_parent[i] = m.dof_parentid[i];
-    d.dof_armature[i] = (float)m.dof_armature[i]; d.dof_damping[i] = (float)m.dof_damping[i];
-    for (int k = 0; k < 2; k++) d.dof_solref[i][k] = (float)m.dof_solref[i][k];
-    for (int k = 0; k < 5; k++) d.dof_solimp[i][k] = (float)m.dof_solimp[i][k];
+    LaneRec& r = d.rec[i];
+    r.d_body = m.dof_bodyid[i]; r.d_parent = m.dof_parentid[i]; r.d_ancmask = anc[i];
+    r.d_armature = (float)m.dof_armature[i]; r.d_damping = (float)m.dof_damping[i];
+    for (int k = 0; k < 2; k++) r.d_solref[k] = (float)m.dof_solref[i][k];
+    for (int k = 0; k < 5; k++) r.d_solimp[k] = (float)m.dof_solimp[i][k];
     int j = m.dof_jntid[i];
-    d.dof_frclimited[i] = m.jnt_type[j] == CS_JNT_HINGE ? m.jnt_actfrclimited[j] : 0;
-    d.dof_frcrange[i][0] = (float)m.jnt_actfrcrange[j][0]; d.dof_frcrange[i][1] = (float)m.jnt_actfrcrange[j][1];
-    d.dof_act[i] = -1;
-    if (m.dof_frictionloss[i] > 0) d.fric_dof[nfric++] = i;
+    r.d_frclimited = m.jnt_type[j] == CS_JNT_HINGE ? m.jnt_actfrclimited[j] : 0;
+    r.d_frcrange[0] = (float)m.jnt_actfrcrange[j][0]; r.d_frcrange[1] = (float)m.jnt_actfrcrange[j][1];
+    r.d_act = -1;
+    if (m.dof_frictionloss[i] > 0) d.rec[nfric++].d_fric = i;
   }
   d.nfric = nfric;
   for (int g = 0; g < m.ngeom; g++) {
-    d.geom_type[g] = m.geom_type[g]; d.geom_body[g] = m.geom_bodyid[g]; d.geom_ground[g] = m.geom_ground[g];
-    d.geom_hulladr[g] = m.geom_hulladr[g]; d.geom_hullnum[g] = m.geom_hullnum[g];
-    d.geom_condim[g] = m.geom_condim[g] > m.ground_condim ? m.geom_condim[g] : m.ground_condim;
-    if (m.geom_ground[g] && d.geom_condim[g] != 3) return fail(COSIM_EINVAL, "only condim 3 contacts are implemented");
-    for (int k = 0; k < 3; k++) { d.geom_pos[g][k] = (float)m.geom_pos[g][k]; d.geom_size[g][k] = (float)m.geom_size[g][k]; d.geom_rcenter[g][k] = (float)m.geom_rcenter[g][k]; }
-    for (int k = 0; k < 4; k++) d.geom_quat[g][k] = (float)m.geom_quat[g][k];
-    d.geom_rbound[g] = (float)m.geom_rbound[g];
+    LaneRec& r = d.rec[g];
+    r.g_type = m.geom_type[g]; r.g_body = m.geom_bodyid[g]; r.g_ground = m.geom_ground[g];
+    r.g_hulladr = m.geom_hulladr[g]; r.g_hullnum = m.geom_hullnum[g];
+    int condim = m.geom_condim[g] > m.ground_condim ? m.geom_condim[g] : m.ground_condim;
+    if (m.geom_ground[g] && condim != 3) return fail(COSIM_EINVAL, "only condim 3 contacts are implemented");
+    for (int k = 0; k < 3; k++) { r.g_pos[k] = (float)m.geom_pos[g][k]; r.g_size[k] = (float)m.geom_size[g][k]; r.g_rcenter[k] = (float)m.geom_rcenter[g][k]; }
+    for (int k = 0; k < 4; k++) r.g_quat[k] = (float)m.geom_quat[g][k];
+    r.g_rbound = (float)m.geom_rbound[g];
     // mj_contactParam with equal priorities: solmix-weighted solref/solimp, margins by max
     double s1 = m.ground_solmix, s2 = m.geom_solmix[g], mix;
     if (s1 >= 1e-15 && s2 >= 1e-15) mix = s1 / (s1 + s2);
     else if (s1 < 1e-15 && s2 < 1e-15) mix = 0.5;
     else mix = s1 < 1e-15 ? 0.0 : 1.0;
     for (int k = 0; k < 2; k++)
-      d.geom_solref[g][k] = (m.ground_solref[0] > 0 && m.geom_solref[g][0] > 0)
-                                ? (float)(mix * m.ground_solref[k] + (1 - mix) * m.geom_solref[g][k])
-                                : (float)fmin(m.ground_solref[k], m.geom_solref[g][k]);
-    for (int k = 0; k < 5; k++) d.geom_solimp[g][k] = (float)(mix * m.ground_solimp[k] + (1 - mix) * m.geom_solimp[g][k]);
+      r.g_solref[k] = (m.ground_solref[0] > 0 && m.geom_solref[g][0] > 0)
+                          ? (float)(mix * m.ground_solref[k] + (1 - mix) * m.geom_solref[g][k])
+                          : (float)fmin(m.ground_solref[k], m.geom_solref[g][k]);
+    for (int k = 0; k < 5; k++) r.g_solimp[k] = (float)(mix * m.ground_solimp[k] + (1 - mix) * m.geom_solimp[g][k]);
     double margin = fmax(m.ground_margin, m.geom_margin[g]), gap = fmax(m.ground_gap, m.geom_gap[g]);
-    d.geom_margin[g] = (float)margin;
-    d.geom_includemargin[g] = (float)(margin - gap);
+    r.g_margin = (float)margin;
+    r.g_incmargin = (float)(margin - gap);
   }
   for (int q = 0; q < m.neq; q++) {
-    d.eq_body1[q] = m.eq_body1[q]; d.eq_body2[q] = m.eq_body2[q];
-    for (int k = 0; k < 3; k++) { d.eq_anchor1[q][k] = (float)m.eq_anchor1[q][k]; d.eq_anchor2[q][k] = (float)m.eq_anchor2[q][k]; }
-    for (int k = 0; k < 2; k++) d.eq_solref[q][k] = (float)m.eq_solref[q][k];
-    for (int k = 0; k < 5; k++) d.eq_solimp[q][k] = (float)m.eq_solimp[q][k];
+    LaneRec& r = d.rec[q];
+    r.e_body1 = m.eq_body1[q]; r.e_body2 = m.eq_body2[q];
+    for (int k = 0; k < 3; k++) { r.e_anchor1[k] = (float)m.eq_anchor1[q][k]; r.e_anchor2[k] = (float)m.eq_anchor2[q][k]; }
+    for (int k = 0; k < 2; k++) r.e_solref[k] = (float)m.eq_solref[q][k];
+    for (int k = 0; k < 5; k++) r.e_solimp[k] = (float)m.eq_solimp[q][k];
   }
   for (int u = 0; u < m.nu; u++) {
-    d.act_dof[u] = m.act_dofid[u]; d.act_ctrllimited[u] = m.act_ctrllimited[u]; d.act_gear[u] = (float)m.act_gear[u];
-    d.act_ctrlrange[u][0] = (float)m.act_ctrlrange[u][0]; d.act_ctrlrange[u][1] = (float)m.act_ctrlrange[u][1];
-    if (d.dof_act[m.act_dofid[u]] >= 0) return fail(COSIM_EINVAL, "two motors on one dof are not supported");
-    d.dof_act[m.act_dofid[u]] = u;
-    d.ctl_velmode[u] = m.ctl_velmode[u]; d.ctl_qadr[u] = m.ctl_qadr[u]; d.ctl_dadr[u] = m.ctl_dadr[u];
-    d.ctl_scale[u] = (float)m.ctl_scale[u]; d.ctl_gear[u] = (float)m.ctl_gear[u]; d.ctl_gamma[u] = (float)m.ctl_gamma[u];
-    d.ctl_maxtq[u] = (float)m.ctl_maxtq[u];
+    LaneRec& r = d.rec[u];
+    r.a_dof = m.act_dofid[u]; r.a_ctrllimited = m.act_ctrllimited[u]; r.a_gear = (float)m.act_gear[u];
+    r.a_ctrlrange[0] = (float)m.act_ctrlrange[u][0]; r.a_ctrlrange[1] = (float)m.act_ctrlrange[u][1];
+    if (d.rec[m.act_dofid[u]].d_act >= 0) return fail(COSIM_EINVAL, "two motors on one dof are not supported");
+    d.rec[m.act_dofid[u]].d_act = u;
+    r.a_velmode = m.ctl_velmode[u]; r.a_qadr = m.ctl_qadr[u]; r.a_dadr = m.ctl_dadr[u];
+    r.a_scale = (float)m.ctl_scale[u]; r.a_cgear = (float)m.ctl_gear[u]; r.a_gamma = (float)m.ctl_gamma[u];
+    r.a_maxtq = (float)m.ctl_maxtq[u];
   }
   d.nobs_pos = m.nobs_pos; d.nobs_vel = m.nobs_vel; d.ninfo_state = m.ninfo_state; d.init_noise_nq = m.init_noise_nq;
-  for (int i = 0; i < CS_MAXOBSJ; i++) { d.obs_qadr[i] = m.obs_qadr[i]; d.obs_dadr[i] = m.obs_dadr[i]; d.obs_qgear[i] = (float)m.obs_qgear[i]; d.obs_dgear[i] = (float)m.obs_dgear[i]; }
-  for (int i = 0; i < CS_MAXINFOSTATE; i++) { d.info_kind[i] = m.info_kind[i]; d.info_adr[i] = m.info_adr[i]; d.info_gear[i] = (float)m.info_gear[i]; }
-  for (int i = 0; i < CS_MAXQ; i++) { d.init_noise_qadr[i] = m.init_noise_qadr[i]; d.init_qpos[i] = (float)m.init_qpos[i]; }
-  for (int i = 0; i < CS_MAXBODY; i++) d.term_body[i] = m.term_body[i];
+  for (int i = 0; i < CS_MAXOBSJ; i++) { d.rec[i].o_qadr = m.obs_qadr[i]; d.rec[i].o_dadr = m.obs_dadr[i]; d.rec[i].o_qgear = (float)m.obs_qgear[i]; d.rec[i].o_dgear = (float)m.obs_dgear[i]; }
+  for (int i = 0; i < CS_MAXINFOSTATE; i++) { d.rec[i].i_kind = m.info_kind[i]; d.rec[i].i_adr = m.info_adr[i]; d.rec[i].i_gear = (float)m.info_gear[i]; }
+  for (int i = 0; i < CS_MAXQ; i++) { d.rec[i].n_qadr = m.init_noise_qadr[i]; d.rec[i].init_qpos = (float)m.init_qpos[i]; }
+  for (int i = 0; i < CS_MAXBODY; i++) d.rec[i].t_body = m.term_body[i];
   d.ntri = m.nv * (m.nv + 1) / 2;
   for (int r = 0, e2 = 0; r < m.nv; r++)
     for (int c = 0; c <= r; c++, e2++) { d.tri_row[e2] = (unsigned char)r; d.tri_col[e2] = (unsigned char)c; }

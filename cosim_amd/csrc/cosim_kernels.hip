@@ -7,19 +7,25 @@
 //   _apply_command_inplace, plus _get_info / _is_done / time limit and (engine extension) in-kernel auto-reset.
 // mj_step itself is MuJoCo's (mujoco==3.2.7, not in the reference tree); the stages below follow its published
 // pipeline (kinematics, comPos, crb, collision, makeConstraint, comVel, rne, fwdActuation, Newton solve with exact
-// line search, implicitfast) re-designed for a 64-lane wave: lanes own bodies / dofs / geoms / constraint rows,
-// intermediates sit in LDS, the nv x nv Newton Hessian is factorised in registers (row i in lane i) with
-// v_readlane broadcasts, and state is read once and written once per control step.
+// line search, implicitfast) re-designed for a 64-lane wave:
+//   * lanes own bodies / dofs / geoms / constraint rows; tree recursions become level sweeps (FK) or sums over
+//     precomputed ancestor / subtree bit masks (no dependent pointer chasing);
+//   * intermediates sit in LDS (<= 10 KB per env -> 16 waves per CU, 4096 envs resident at once on 256 CUs);
+//   * the nv x nv Newton Hessian is assembled entry-parallel, then factorised in registers (row i in lane i) with
+//     v_readlane broadcasts; reductions use DPP row operations;
+//   * per-env state is one contiguous HBM record, read once and written once per control step.
 #include "cosim_dev.h"
 
 namespace cosim {
 
-#define WSYNC()                                          \
-  do {                                                   \
+#define WSYNC()                                            \
+  do {                                                     \
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); \
-    __builtin_amdgcn_wave_barrier();                     \
+    __builtin_amdgcn_wave_barrier();                       \
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); \
   } while (0)
+// hide the lane id from loop-invariant code motion: address arithmetic stays local to the phase that uses it
+#define LAUNDER(x) asm volatile("" : "+v"(x))
 
 constexpr float MINVAL = 1e-15f;
 constexpr float MINIMP = 0.0001f, MAXIMP = 0.9999f;
@@ -56,16 +62,32 @@ struct KArgs {
 // ------------------------------------------------------------------------------------------------ wave helpers
 __device__ __forceinline__ float rl(float v, int lane) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane)); }
 __device__ __forceinline__ float rfl(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
-__device__ __forceinline__ int rfli(int v) { return __builtin_amdgcn_readfirstlane(v); }
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+template <int CTRL>
+__device__ __forceinline__ float dpp(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, false));
+}
+// sum over the 16 lanes of a DPP row, result in every lane of the row (quad_perm xor 1, xor 2, half mirror, mirror)
+__device__ __forceinline__ float row_sum(float v) {
+  v += dpp<0xB1>(v);
+  v += dpp<0x4E>(v);
+  v += dpp<0x141>(v);
+  v += dpp<0x140>(v);
   return v;
 }
+__device__ __forceinline__ float wave_sum(float v) {
+  v = row_sum(v);
+  float s = rl(v, 0);
+  s += rl(v, 16);
+  s += rl(v, 32);
+  s += rl(v, 48);
+  return s;
+}
 __device__ __forceinline__ float wave_min(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
-  return v;
+  v = fminf(v, dpp<0xB1>(v));
+  v = fminf(v, dpp<0x4E>(v));
+  v = fminf(v, dpp<0x141>(v));
+  v = fminf(v, dpp<0x140>(v));
+  return fminf(fminf(rl(v, 0), rl(v, 16)), fminf(rl(v, 32), rl(v, 48)));
 }
 __device__ __forceinline__ unsigned long long lanemask_lt(int lane) { return (1ull << lane) - 1ull; }
 
@@ -120,8 +142,8 @@ __device__ __forceinline__ void make_frame(const float* n, float* t1, float* t2)
   cross(t2, n, t1);
 }
 
-// Philox4x32-10, counter-based: key = (seed, global env id), counter = (step, purpose, index, 0)
-__device__ __forceinline__ void philox(unsigned k0, unsigned k1, unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned* out) {
+// Philox4x32-10, counter-based: key = (seed, global env id), counter = (step, purpose, index, 0); first output word
+__device__ __forceinline__ unsigned philox_first(unsigned k0, unsigned k1, unsigned c0, unsigned c1, unsigned c2, unsigned c3) {
 #pragma unroll
   for (int r = 0; r < 10; r++) {
     unsigned hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
@@ -130,34 +152,38 @@ __device__ __forceinline__ void philox(unsigned k0, unsigned k1, unsigned c0, un
     c0 = n0; c1 = n1; c2 = n2; c3 = n3;
     k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
   }
-  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+  return c0;
 }
 __device__ __forceinline__ float u01(unsigned x) { return (float)(x >> 8) * (1.0f / 16777216.0f) + (0.5f / 16777216.0f); }  // (0,1)
 
 // ------------------------------------------------------------------------------------------------ LDS per env
 template <int NV, int NB>
 struct EnvLds {
-  static constexpr int LDJ = NV | 1;
-  static constexpr int TRI = NV * (NV + 1) / 2;
-  static constexpr int MC = 14;  // contact slots
-  float qpos[CS_MAXQ], qvel[NV], qacc[NV], qact[NV], qsm[NV], qcon[NV], Ma[NV], Mv[NV], sr[NV], dofD[NV], qbias[NV];
+  static constexpr int LD = NV | 1;   // odd leading dimension: conflict-free column access
+  static constexpr int MC = 12;       // contact slots (4 pyramid rows each)
+  static constexpr int NGEN = 3 * MAXEQ / 2 + 4 * MC;  // dense rows: 2 connect equalities (6 rows) + contacts
+  static constexpr int NLIM = 8;
+  float qpos[CS_MAXQ], qvel[NV], qacc[NV], qact[NV], qsm[NV], qcon[NV], sr[NV], dofD[NV];
   float xpos[NB][3], xquat[NB][4], xanc[NB][3], xax[NB][3];
-  float cin[NB][10], cfb[NB][6];
-  float cdof[NV][6], cdd[NV][6];
-  float M[TRI], H[TRI];
-  float J[MAXROW][LDJ];
-  float rowf[MAXROW], rowD[MAXROW];
-  float cpos[MC][3], cnrm[MC][3], cdist[MC], cmu[MC];
+  float cdof[NV][6];
+  float M[NV][LD];
+  union {                      // scratch that is dead before the solver starts shares the Hessian's space
+    float H[NV][LD];
+    struct { float cdd[NV][6], cfb[NB][6]; } v;
+  } u;
+  union {
+    float cin[NB][10];         // dead after the bias forces
+    struct { float rowf[MAXROW], rowD[MAXROW]; } r;
+  } w;
+  float J[NGEN][LD];
+  float cpos[MC][3], cnrm[MC][3], cdist[MC];
   int cgeom[MC];
-  int lim_body[MAXROW];
-  float lim_sign[MAXROW], lim_dist[MAXROW];
-  float p_mass[NB], p_binvw[NB], p_dinvw[NV], p_floss[NV], p_gmu[MAXG];
-  float act[MAXU], cmd[CS_MAXCMD];
-  float com[3];
+  int lim_body[NLIM];
+  float lim_sign[NLIM], lim_dist[NLIM];
+  float p_mass[NB], p_binvw[NB], p_dinvw[NV], p_floss[NV], p_gmu[32];
+  float act[MAXU], cmd[CS_MAXCMD + 2];
+  float com[4];
 };
-
-// index of (i, k) in the packed lower triangle
-__device__ __forceinline__ int tri_idx(int i, int k) { return i >= k ? (i * (i + 1)) / 2 + k : (k * (k + 1)) / 2 + i; }
 
 // ------------------------------------------------------------------------------------------------ Cholesky in registers
 // Lane i < NV holds row i of a symmetric positive definite matrix in a[0..NV).  On exit a[k], k <= i, is L[i][k] and
@@ -211,6 +237,7 @@ __device__ __forceinline__ float impedance(const float* solimp, float pos, float
   if (x <= 0.f) return d0;
   float y;
   if (power == 1.f) y = x;
+  else if (power == 2.f) y = x <= mid ? x * x / mid : 1.f - (1.f - x) * (1.f - x) / (1.f - mid);
   else if (x <= mid) y = powf(x, power) / powf(mid, power - 1.f);
   else y = 1.f - powf(1.f - x, power) / powf(1.f - mid, power - 1.f);
   return d0 + y * (d1 - d0);
@@ -220,9 +247,9 @@ __device__ __forceinline__ float impedance(const float* solimp, float pos, float
 template <int NV, int NB>
 __global__ __launch_bounds__(64, 4) void env_kernel(KArgs A) {
   using L = EnvLds<NV, NB>;
-  constexpr int LDJ = L::LDJ;
-  constexpr int TRI = L::TRI;
+  constexpr int TRI = NV * (NV + 1) / 2;
   constexpr int MC = L::MC;
+  constexpr int NGENMAX = L::NGEN;
   constexpr int EPL = (TRI + 63) / 64;
   __shared__ L S;
   const int lane = threadIdx.x;
@@ -233,17 +260,17 @@ __global__ __launch_bounds__(64, 4) void env_kernel(KArgs A) {
   const Layout lay = A.lay;
   float* rec = A.state + (size_t)env * lay.s_stride;
   const float* par = A.params + (size_t)env * lay.p_stride;
-  const int nv = NV, nbody = dm.nbody, nu = dm.nu, nq = dm.nq, ngeom = dm.ngeom;
+  const int nbody = dm.nbody, nu = dm.nu, nq = dm.nq, ngeom = dm.ngeom;
   const float h = dm.timestep;
 
   // ---- per-env parameters -> LDS
   if (lane < nbody) { S.p_mass[lane] = par[lay.p_mass + lane]; S.p_binvw[lane] = par[lay.p_binvw + lane]; }
-  if (lane < nv) { S.p_dinvw[lane] = par[lay.p_dinvw + lane]; S.p_floss[lane] = par[lay.p_floss + lane]; }
+  if (lane < NV) { S.p_dinvw[lane] = par[lay.p_dinvw + lane]; S.p_floss[lane] = par[lay.p_floss + lane]; }
   if (lane < ngeom) S.p_gmu[lane] = par[lay.p_gmu + lane];
   const float meaninertia = par[lay.p_mean];
   int* meta = reinterpret_cast<int*>(rec + lay.s_meta);
   int sim_step = meta[0];
-  unsigned step_count = (unsigned)meta[1];
+  const unsigned step_count = (unsigned)meta[1];
   int has_prev = meta[2];
   const unsigned long long gid = (unsigned long long)(A.env_id0 + env);
   const unsigned k0 = A.seed_lo ^ (unsigned)gid, k1 = A.seed_hi ^ (unsigned)(gid >> 32);
@@ -255,19 +282,21 @@ __global__ __launch_bounds__(64, 4) void env_kernel(KArgs A) {
   }
 
   // ---- applied command (CommandWrapper.receive_user_command, wrappers.py:349-375) from the pre-step pose
-  float applied_cmd = 0.f;  // lane c < command_dim
-  if (lane < ob.command_dim && A.commands != nullptr) {
-    float uc = A.commands[(size_t)env * ob.command_dim + lane];
-    if (!ob.position_command) applied_cmd = uc * ob.command_scales[lane];
-    else {
-      float px = rec[lay.s_qpos + 0], py = rec[lay.s_qpos + 1];
-      float w = rec[lay.s_qpos + 3], x = rec[lay.s_qpos + 4], y = rec[lay.s_qpos + 5], z = rec[lay.s_qpos + 6];
-      float tx = A.commands[(size_t)env * ob.command_dim + 0], ty = A.commands[(size_t)env * ob.command_dim + 1];
-      float dx = tx - px, dy = ty - py;
-      float yaw = atan2f(2.f * (w * z + x * y), 1.f - 2.f * (y * y + z * z));
-      float cy = cosf(-yaw), sy = sinf(-yaw);
-      applied_cmd = lane == 0 ? cy * dx - sy * dy : sy * dx + cy * dy;
+  if (lane < CS_MAXCMD) {
+    float applied = 0.f;
+    if (lane < ob.command_dim && A.commands != nullptr) {
+      const float* uc = A.commands + (size_t)env * ob.command_dim;
+      if (!ob.position_command) applied = uc[lane] * ob.command_scales[lane];
+      else {
+        float px = rec[lay.s_qpos + 0], py = rec[lay.s_qpos + 1];
+        float w = rec[lay.s_qpos + 3], x = rec[lay.s_qpos + 4], y = rec[lay.s_qpos + 5], z = rec[lay.s_qpos + 6];
+        float dx = uc[0] - px, dy = uc[1] - py;
+        float yaw = atan2f(2.f * (w * z + x * y), 1.f - 2.f * (y * y + z * z));
+        float cy = cosf(-yaw), sy = sinf(-yaw);
+        applied = lane == 0 ? cy * dx - sy * dy : sy * dx + cy * dy;
+      }
     }
+    S.cmd[lane] = applied;
   }
 
   // sensor values of the last forward pass (uniform across the wave)
@@ -280,31 +309,31 @@ __global__ __launch_bounds__(64, 4) void env_kernel(KArgs A) {
   if (A.mode != MODE_RESET) {
     // ---- state -> LDS
     if (lane < nq) S.qpos[lane] = rec[lay.s_qpos + lane];
-    if (lane < nv) { S.qvel[lane] = rec[lay.s_qvel + lane]; S.qacc[lane] = rec[lay.s_warm + lane]; S.qact[lane] = 0.f; }
+    if (lane < NV) { S.qvel[lane] = rec[lay.s_qvel + lane]; S.qacc[lane] = rec[lay.s_warm + lane]; S.qact[lane] = 0.f; }
     WSYNC();
 
     // ---- control (once per control step): delay filter + PD, zero-order hold over the substeps
     if (A.mode == MODE_STEP) {
-      unsigned rnd[4];
-      philox(k0, k1, step_count, 0u, 0u, 0u, rnd);
-      const bool delayed = (ob.action_delay_prob > u01(rnd[0])) && has_prev;  // control_manager.py:15-23
+      const bool delayed = (ob.action_delay_prob > u01(philox_first(k0, k1, step_count, 0u, 0u, 0u))) && has_prev;  // control_manager.py:15-23
       if (lane < nu) {
+        const LaneRec& R = dm.rec[lane];
         raw_action = A.actions[(size_t)env * nu + lane];
         prev_action = rec[lay.s_lastact + lane];
         float filt = delayed ? rec[lay.s_delay + lane] : raw_action;
         rec[lay.s_delay + lane] = raw_action;
-        float a = filt * dm.ctl_scale[lane], g = dm.ctl_gear[lane];
-        float q = S.qpos[dm.ctl_qadr[lane]] * g, qd = S.qvel[dm.ctl_dadr[lane]] * g;
+        float a = filt * R.a_scale, g = R.a_cgear;
+        float q = S.qpos[R.a_qadr] * g, qd = S.qvel[R.a_dadr] * g;
         float kp = par[lay.p_kp + lane], kd = par[lay.p_kd + lane];
-        float t = dm.ctl_velmode[lane] ? kd * (a - qd) : kp * (a - q) + kd * (0.f - qd);
-        t *= dm.ctl_gamma[lane];
-        t = fminf(dm.ctl_maxtq[lane], fmaxf(-dm.ctl_maxtq[lane], t));
+        float t = R.a_velmode ? kd * (a - qd) : kp * (a - q) + kd * (0.f - qd);
+        t *= R.a_gamma;
+        t = fminf(R.a_maxtq, fmaxf(-R.a_maxtq, t));
         tq_lane = t;
         // mj_fwdActuation: ctrl clamp, gear, then the joint-level actuatorfrcrange clamp (one motor per dof)
-        float c = dm.act_ctrllimited[lane] ? fminf(dm.act_ctrlrange[lane][1], fmaxf(dm.act_ctrlrange[lane][0], t)) : t;
-        float f = dm.act_gear[lane] * c;
-        int d = dm.act_dof[lane];
-        if (dm.dof_frclimited[d]) f = fminf(dm.dof_frcrange[d][1], fmaxf(dm.dof_frcrange[d][0], f));
+        float c = R.a_ctrllimited ? fminf(R.a_ctrlrange[1], fmaxf(R.a_ctrlrange[0], t)) : t;
+        float f = R.a_gear * c;
+        const int d = R.a_dof;
+        const LaneRec& RD = dm.rec[d];
+        if (RD.d_frclimited) f = fminf(RD.d_frcrange[1], fmaxf(RD.d_frcrange[0], f));
         S.qact[d] = f;
       }
       has_prev = 1;
@@ -313,162 +342,181 @@ __global__ __launch_bounds__(64, 4) void env_kernel(KArgs A) {
     }
 
     const int nsub = A.mode == MODE_DEBUG ? 1 : dm.frame_skip;
+#pragma nounroll
     for (int sub = 0; sub < nsub; sub++) {
+      int ln = lane;
+      LAUNDER(ln);
       // =========================================================== mj_kinematics: level-synchronous over the tree
-      const int b_level = lane < nbody ? dm.body_level[lane] : -1;
-      for (int lev = 1; lev <= dm.maxdepth; lev++) {
-        if (b_level == lev) {
-          const int b = lane, jt = dm.body_jtype[b];
-          float xp[3], xq[4], anc[3] = {0.f, 0.f, 0.f}, ax[3] = {0.f, 0.f, 1.f};
-          if (jt == CS_JNT_FREE) {
-            const int qa = dm.body_qadr[b];
-            for (int k = 0; k < 3; k++) xp[k] = S.qpos[qa + k];
-            for (int k = 0; k < 4; k++) xq[k] = S.qpos[qa + 3 + k];
-            qnorm(xq);
-            for (int k = 0; k < 3; k++) { anc[k] = xp[k]; ax[k] = dm.jnt_axis[b][k]; }
-          } else {
-            const int p = dm.body_parent[b];
-            float pq[4] = {S.xquat[p][0], S.xquat[p][1], S.xquat[p][2], S.xquat[p][3]};
-            float v[3];
-            qrot(v, pq, dm.body_pos[b]);
-            for (int k = 0; k < 3; k++) xp[k] = S.xpos[p][k] + v[k];
-            qmul(xq, pq, dm.body_quat[b]);
-            if (jt == CS_JNT_HINGE) {
-              qrot(v, xq, dm.jnt_pos[b]);
-              for (int k = 0; k < 3; k++) anc[k] = xp[k] + v[k];
-              qrot(ax, xq, dm.jnt_axis[b]);
-              float ang = S.qpos[dm.body_qadr[b]] - dm.jnt_q0[b];
-              float sn, cs;
-              sincosf(0.5f * ang, &sn, &cs);
-              float ql[4] = {cs, dm.jnt_axis[b][0] * sn, dm.jnt_axis[b][1] * sn, dm.jnt_axis[b][2] * sn};
-              qmul(xq, xq, ql);
-              qrot(v, xq, dm.jnt_pos[b]);
-              for (int k = 0; k < 3; k++) xp[k] = anc[k] - v[k];
+      {
+        const LaneRec& R = dm.rec[ln];
+        const int b_level = ln < nbody ? R.b_level : -1;
+        const int maxdepth = dm.maxdepth;
+        for (int lev = 1; lev <= maxdepth; lev++) {
+          if (b_level == lev) {
+            const int b = ln, jt = R.b_jtype;
+            float xp[3], xq[4], anc[3] = {0.f, 0.f, 0.f}, ax[3] = {0.f, 0.f, 1.f};
+            if (jt == CS_JNT_FREE) {
+              const int qa = R.b_qadr;
+              for (int k = 0; k < 3; k++) xp[k] = S.qpos[qa + k];
+              for (int k = 0; k < 4; k++) xq[k] = S.qpos[qa + 3 + k];
+              qnorm(xq);
+              for (int k = 0; k < 3; k++) { anc[k] = xp[k]; ax[k] = R.j_axis[k]; }
+            } else {
+              const int p = R.b_parent;
+              float pq[4] = {S.xquat[p][0], S.xquat[p][1], S.xquat[p][2], S.xquat[p][3]};
+              float v[3];
+              qrot(v, pq, R.b_pos);
+              for (int k = 0; k < 3; k++) xp[k] = S.xpos[p][k] + v[k];
+              qmul(xq, pq, R.b_quat);
+              if (jt == CS_JNT_HINGE) {
+                qrot(v, xq, R.j_pos);
+                for (int k = 0; k < 3; k++) anc[k] = xp[k] + v[k];
+                qrot(ax, xq, R.j_axis);
+                float ang = S.qpos[R.b_qadr] - R.j_q0;
+                float sn, cs;
+                sincosf(0.5f * ang, &sn, &cs);
+                float ql[4] = {cs, R.j_axis[0] * sn, R.j_axis[1] * sn, R.j_axis[2] * sn};
+                qmul(xq, xq, ql);
+                qrot(v, xq, R.j_pos);
+                for (int k = 0; k < 3; k++) xp[k] = anc[k] - v[k];
+              }
+              qnorm(xq);
             }
-            qnorm(xq);
+            for (int k = 0; k < 3; k++) { S.xpos[b][k] = xp[k]; S.xanc[b][k] = anc[k]; S.xax[b][k] = ax[k]; }
+            for (int k = 0; k < 4; k++) S.xquat[b][k] = xq[k];
           }
-          for (int k = 0; k < 3; k++) { S.xpos[b][k] = xp[k]; S.xanc[b][k] = anc[k]; S.xax[b][k] = ax[k]; }
-          for (int k = 0; k < 4; k++) S.xquat[b][k] = xq[k];
+          if (ln == 0 && lev == 1) {
+            S.xpos[0][0] = S.xpos[0][1] = S.xpos[0][2] = 0.f;
+            S.xquat[0][0] = 1.f; S.xquat[0][1] = S.xquat[0][2] = S.xquat[0][3] = 0.f;
+          }
+          WSYNC();
         }
-        if (lane == 0 && lev == 1) {
-          S.xpos[0][0] = S.xpos[0][1] = S.xpos[0][2] = 0.f;
-          S.xquat[0][0] = 1.f; S.xquat[0][1] = S.xquat[0][2] = S.xquat[0][3] = 0.f;
-        }
-        WSYNC();
       }
 
       // =========================================================== mj_comPos: com, cinert (lane = body)
       float cinert[10];
 #pragma unroll
       for (int k = 0; k < 10; k++) cinert[k] = 0.f;
-      float xip[3] = {0.f, 0.f, 0.f}, bmass = 0.f, ximat[9];
-      if (lane > 0 && lane < nbody) {
-        const int b = lane;
-        float xq[4] = {S.xquat[b][0], S.xquat[b][1], S.xquat[b][2], S.xquat[b][3]};
-        float v[3], qi[4];
-        qrot(v, xq, dm.body_ipos[b]);
-        for (int k = 0; k < 3; k++) xip[k] = S.xpos[b][k] + v[k];
-        qmul(qi, xq, dm.body_iquat[b]);
-        q2m(ximat, qi);
-        bmass = S.p_mass[b];
-      }
       {
-        float sx = wave_sum(bmass * xip[0]), sy = wave_sum(bmass * xip[1]), sz = wave_sum(bmass * xip[2]), sm = wave_sum(bmass);
-        float inv = 1.f / fmaxf(sm, 1e-20f);
-        if (lane == 0) { S.com[0] = sx * inv; S.com[1] = sy * inv; S.com[2] = sz * inv; }
+        const LaneRec& R = dm.rec[ln];
+        float xip[3] = {0.f, 0.f, 0.f}, bmass = 0.f, ximat[9];
+#pragma unroll
+        for (int k = 0; k < 9; k++) ximat[k] = 0.f;
+        if (ln > 0 && ln < nbody) {
+          const int b = ln;
+          float xq[4] = {S.xquat[b][0], S.xquat[b][1], S.xquat[b][2], S.xquat[b][3]};
+          float v[3], qi[4];
+          qrot(v, xq, R.b_ipos);
+          for (int k = 0; k < 3; k++) xip[k] = S.xpos[b][k] + v[k];
+          qmul(qi, xq, R.b_iquat);
+          q2m(ximat, qi);
+          bmass = S.p_mass[b];
+        }
+        const float sx = wave_sum(bmass * xip[0]), sy = wave_sum(bmass * xip[1]), sz = wave_sum(bmass * xip[2]), sm = wave_sum(bmass);
+        const float inv = 1.f / fmaxf(sm, 1e-20f);
+        const float c0 = sx * inv, c1 = sy * inv, c2 = sz * inv;
+        if (ln == 0) { S.com[0] = c0; S.com[1] = c1; S.com[2] = c2; }
+        if (ln > 0 && ln < nbody) {
+          const float* I = R.b_inertia;
+          float dif[3] = {xip[0] - c0, xip[1] - c1, xip[2] - c2};
+          float Rm[9];
+#pragma unroll
+          for (int r = 0; r < 3; r++)
+#pragma unroll
+            for (int c = 0; c < 3; c++)
+              Rm[3 * r + c] = ximat[3 * r] * I[0] * ximat[3 * c] + ximat[3 * r + 1] * I[1] * ximat[3 * c + 1] + ximat[3 * r + 2] * I[2] * ximat[3 * c + 2];
+          float dd = dot3(dif, dif);
+          cinert[0] = Rm[0] + bmass * (dd - dif[0] * dif[0]);
+          cinert[1] = Rm[4] + bmass * (dd - dif[1] * dif[1]);
+          cinert[2] = Rm[8] + bmass * (dd - dif[2] * dif[2]);
+          cinert[3] = Rm[1] - bmass * dif[0] * dif[1];
+          cinert[4] = Rm[2] - bmass * dif[0] * dif[2];
+          cinert[5] = Rm[5] - bmass * dif[1] * dif[2];
+          cinert[6] = bmass * dif[0]; cinert[7] = bmass * dif[1]; cinert[8] = bmass * dif[2];
+          cinert[9] = bmass;
+        }
+        if (ln < nbody) {
+#pragma unroll
+          for (int k = 0; k < 10; k++) S.w.cin[ln][k] = cinert[k];
+        }
       }
       WSYNC();
       const float com[3] = {S.com[0], S.com[1], S.com[2]};
-      if (lane > 0 && lane < nbody) {
-        const int b = lane;
-        const float* I = dm.body_inertia[b];
-        float dif[3] = {xip[0] - com[0], xip[1] - com[1], xip[2] - com[2]};
-        float R[9];
-#pragma unroll
-        for (int r = 0; r < 3; r++)
-#pragma unroll
-          for (int c = 0; c < 3; c++)
-            R[3 * r + c] = ximat[3 * r] * I[0] * ximat[3 * c] + ximat[3 * r + 1] * I[1] * ximat[3 * c + 1] + ximat[3 * r + 2] * I[2] * ximat[3 * c + 2];
-        float dd = dot3(dif, dif);
-        cinert[0] = R[0] + bmass * (dd - dif[0] * dif[0]);
-        cinert[1] = R[4] + bmass * (dd - dif[1] * dif[1]);
-        cinert[2] = R[8] + bmass * (dd - dif[2] * dif[2]);
-        cinert[3] = R[1] - bmass * dif[0] * dif[1];
-        cinert[4] = R[2] - bmass * dif[0] * dif[2];
-        cinert[5] = R[5] - bmass * dif[1] * dif[2];
-        cinert[6] = bmass * dif[0]; cinert[7] = bmass * dif[1]; cinert[8] = bmass * dif[2];
-        cinert[9] = bmass;
-      }
-      if (lane < nbody) {
-#pragma unroll
-        for (int k = 0; k < 10; k++) S.cin[lane][k] = cinert[k];
-      }
       // cdof (lane = dof)
       float cd[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-      int d_body = 0, d_parent = -1;
-      if (lane < nv) {
-        d_body = dm.dof_body[lane];
-        d_parent = dm.dof_parent[lane];
-        const int b = d_body, jt = dm.body_jtype[b], k = lane - dm.body_dadr[b];
-        if (jt == CS_JNT_FREE) {
-          if (k < 3) cd[3 + k] = 1.f;
-          else {
-            float m[9], xq[4] = {S.xquat[b][0], S.xquat[b][1], S.xquat[b][2], S.xquat[b][3]};
-            q2m(m, xq);
-            float axs[3] = {m[k - 3], m[3 + k - 3], m[6 + k - 3]};
-            float off[3] = {com[0] - S.xpos[b][0], com[1] - S.xpos[b][1], com[2] - S.xpos[b][2]};
+      float qv = 0.f;
+      {
+        const LaneRec& R = dm.rec[ln];
+        if (ln < NV) {
+          qv = S.qvel[ln];
+          const int b = R.d_body;
+          const LaneRec& RB = dm.rec[b];
+          const int jt = RB.b_jtype, k = ln - RB.b_dadr;
+          if (jt == CS_JNT_FREE) {
+            if (k < 3) cd[3 + k] = 1.f;
+            else {
+              float m[9], xq[4] = {S.xquat[b][0], S.xquat[b][1], S.xquat[b][2], S.xquat[b][3]};
+              q2m(m, xq);
+              float axs[3] = {m[k - 3], m[3 + k - 3], m[6 + k - 3]};
+              float off[3] = {com[0] - S.xpos[b][0], com[1] - S.xpos[b][1], com[2] - S.xpos[b][2]};
+              cd[0] = axs[0]; cd[1] = axs[1]; cd[2] = axs[2];
+              cross(cd + 3, axs, off);
+            }
+          } else {
+            float axs[3] = {S.xax[b][0], S.xax[b][1], S.xax[b][2]};
+            float off[3] = {com[0] - S.xanc[b][0], com[1] - S.xanc[b][1], com[2] - S.xanc[b][2]};
             cd[0] = axs[0]; cd[1] = axs[1]; cd[2] = axs[2];
             cross(cd + 3, axs, off);
           }
-        } else {
-          float axs[3] = {S.xax[b][0], S.xax[b][1], S.xax[b][2]};
-          float off[3] = {com[0] - S.xanc[b][0], com[1] - S.xanc[b][1], com[2] - S.xanc[b][2]};
-          cd[0] = axs[0]; cd[1] = axs[1]; cd[2] = axs[2];
-          cross(cd + 3, axs, off);
-        }
 #pragma unroll
-        for (int q = 0; q < 6; q++) S.cdof[lane][q] = cd[q];
+          for (int q = 0; q < 6; q++) S.cdof[ln][q] = cd[q];
+#pragma unroll
+          for (int k2 = 0; k2 < NV; k2++) S.M[ln][k2] = 0.f;
+        }
       }
-      for (int e = lane; e < TRI; e += 64) S.M[e] = 0.f;
       WSYNC();
 
-      // =========================================================== mj_crb: composite inertia of the dof's body, M row
-      if (lane < nv) {
+      // =========================================================== mj_crb: composite inertia of the dof's body, M row + column
+      if (ln < NV) {
+        const LaneRec& R = dm.rec[ln];
         float crb[10];
 #pragma unroll
         for (int k = 0; k < 10; k++) crb[k] = 0.f;
-        unsigned sub_mask = dm.body_subtree[d_body];
-        for (int c = 1; c < nbody; c++)
-          if ((sub_mask >> c) & 1u) {
+        for (unsigned mk = dm.rec[R.d_body].b_subtree; mk; mk &= mk - 1) {
+          const int c = __builtin_ctz(mk);
 #pragma unroll
-            for (int k = 0; k < 10; k++) crb[k] += S.cin[c][k];
-          }
+          for (int k = 0; k < 10; k++) crb[k] += S.w.cin[c][k];
+        }
         float buf[6];
         mul_inert(buf, crb, cd);
-        for (int j = lane; j >= 0; j = dm.dof_parent[j]) {
+        for (unsigned mk = R.d_ancmask; mk; mk &= mk - 1) {
+          const int j = __builtin_ctz(mk);
           float v = 0.f;
 #pragma unroll
           for (int q = 0; q < 6; q++) v += S.cdof[j][q] * buf[q];
-          if (j == lane) v += dm.dof_armature[lane];
-          S.M[(lane * (lane + 1)) / 2 + j] = v;
+          if (j == ln) v += R.d_armature;
+          S.M[ln][j] = v;
+          S.M[j][ln] = v;
         }
       }
 
       // =========================================================== mj_comVel + mj_rne (bias) + passive + smooth force
-      float qv = lane < nv ? S.qvel[lane] : 0.f;
-      if (lane < nv) {
+      if (ln < NV) {
+        const LaneRec& R = dm.rec[ln];
         // velocity of the parent chain just before this dof (free joint: rotations see the translational part only)
         float cv[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        const int b = d_body, jt = dm.body_jtype[b], k = lane - dm.body_dadr[b];
+        const LaneRec& RB = dm.rec[R.d_body];
+        const int jt = RB.b_jtype, k = ln - RB.b_dadr;
         float cdd[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         if (jt == CS_JNT_FREE) {
           if (k >= 3) {
-            const int d0 = dm.body_dadr[b];
+            const int d0 = RB.b_dadr;
             cv[3] = S.qvel[d0]; cv[4] = S.qvel[d0 + 1]; cv[5] = S.qvel[d0 + 2];
           }
         } else {
-          for (int j = d_parent; j >= 0; j = dm.dof_parent[j]) {
-            float qj = S.qvel[j];
+          for (unsigned mk = R.d_ancmask & ~(1u << ln); mk; mk &= mk - 1) {
+            const int j = __builtin_ctz(mk);
+            const float qj = S.qvel[j];
 #pragma unroll
             for (int q = 0; q < 6; q++) cv[q] += S.cdof[j][q] * qj;
           }
@@ -482,16 +530,18 @@ __global__ __launch_bounds__(64, 4) void env_kernel(KArgs A) {
           cdd[3] = bb[0] + c[0]; cdd[4] = bb[1] + c[1]; cdd[5] = bb[2] + c[2];
         }
 #pragma unroll
-        for (int q = 0; q < 6; q++) S.cdd[lane][q] = cdd[q];
+        for (int q = 0; q < 6; q++) S.u.v.cdd[ln][q] = cdd[q];
       }
       WSYNC();
-      float cvel_b[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-      if (lane > 0 && lane < nbody) {
+      if (ln > 0 && ln < nbody) {
+        const LaneRec& R = dm.rec[ln];
+        float cvel_b[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         float cacc[6] = {0.f, 0.f, 0.f, -dm.gravity[0], -dm.gravity[1], -dm.gravity[2]};
-        for (int j = dm.body_lastdof[lane]; j >= 0; j = dm.dof_parent[j]) {
-          float qj = S.qvel[j];
+        for (unsigned mk = R.b_dofmask; mk; mk &= mk - 1) {
+          const int j = __builtin_ctz(mk);
+          const float qj = S.qvel[j];
 #pragma unroll
-          for (int q = 0; q < 6; q++) { cvel_b[q] += S.cdof[j][q] * qj; cacc[q] += S.cdd[j][q] * qj; }
+          for (int q = 0; q < 6; q++) { cvel_b[q] += S.cdof[j][q] * qj; cacc[q] += S.u.v.cdd[j][q] * qj; }
         }
         float t1[6], t2[6], t3[6];
         mul_inert(t1, cinert, cacc);
@@ -505,33 +555,34 @@ __global__ __launch_bounds__(64, 4) void env_kernel(KArgs A) {
           t3[3] = c[0]; t3[4] = c[1]; t3[5] = c[2];
         }
 #pragma unroll
-        for (int q = 0; q < 6; q++) S.cfb[lane][q] = t1[q] + t3[q];
+        for (int q = 0; q < 6; q++) S.u.v.cfb[ln][q] = t1[q] + t3[q];
       }
       WSYNC();
-      if (lane < nv) {
+      if (ln < NV) {
+        const LaneRec& R = dm.rec[ln];
         float f[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        unsigned sub_mask = dm.body_subtree[d_body];
-        for (int c = 1; c < nbody; c++)
-          if ((sub_mask >> c) & 1u) {
+        for (unsigned mk = dm.rec[R.d_body].b_subtree; mk; mk &= mk - 1) {
+          const int c = __builtin_ctz(mk);
 #pragma unroll
-            for (int q = 0; q < 6; q++) f[q] += S.cfb[c][q];
-          }
+          for (int q = 0; q < 6; q++) f[q] += S.u.v.cfb[c][q];
+        }
         float bias = 0.f;
 #pragma unroll
         for (int q = 0; q < 6; q++) bias += cd[q] * f[q];
-        S.qbias[lane] = bias;
-        S.qsm[lane] = -dm.dof_damping[lane] * qv - bias + S.qact[lane];
+        S.qsm[ln] = -R.d_damping * qv - bias + S.qact[ln];
+        if (A.mode == MODE_DEBUG && A.dbg != nullptr) A.dbg[1140 + ln] = bias;
       }
 
-      // sensors of this forward pass (framequat, gyro, velocimeter on the IMU site); uniform code
-      {
+      // sensors of this forward pass (framequat, gyro, velocimeter on the IMU site); only the last substep's are read
+      if (sub == nsub - 1) {
         const int ib = dm.imu_body;
         float xq[4] = {S.xquat[ib][0], S.xquat[ib][1], S.xquat[ib][2], S.xquat[ib][3]};
         qmul(s_quat, xq, dm.imu_quat);
         qnorm(s_quat);
         float cv[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        for (int j = dm.body_lastdof[ib]; j >= 0; j = dm.dof_parent[j]) {
-          float qj = S.qvel[j];
+        for (unsigned mk = dm.imu_dofmask; mk; mk &= mk - 1) {
+          const int j = __builtin_ctz(mk);
+          const float qj = S.qvel[j];
 #pragma unroll
           for (int q = 0; q < 6; q++) cv[q] += S.cdof[j][q] * qj;
         }
@@ -553,25 +604,27 @@ __global__ __launch_bounds__(64, 4) void env_kernel(KArgs A) {
       // =========================================================== collision: ground plane vs robot geoms (lane = geom)
       int ncon = 0;
       {
+        const LaneRec& R = dm.rec[ln];
         float cp[4][3], cdst[4];
         int cnt = 0;
         bool mesh_near = false;
         const float n[3] = {0.f, 0.f, 1.f};
-        if (lane < ngeom && dm.geom_ground[lane]) {
-          const int g = lane, b = dm.geom_body[g], gt = dm.geom_type[g];
+        const float gz = dm.ground_pos[2];
+        if (ln < ngeom && R.g_ground) {
+          const int b = R.g_body, gt = R.g_type;
           float xq[4] = {S.xquat[b][0], S.xquat[b][1], S.xquat[b][2], S.xquat[b][3]};
-          const float margin = dm.geom_margin[g];
+          const float margin = R.g_margin;
           if (gt == CS_GEOM_MESH) {
             float v[3];
-            qrot(v, xq, dm.geom_rcenter[g]);
-            mesh_near = (S.xpos[b][2] + v[2] - dm.ground_pos[2] - dm.geom_rbound[g]) <= margin;
+            qrot(v, xq, R.g_rcenter);
+            mesh_near = (S.xpos[b][2] + v[2] - gz - R.g_rbound) <= margin;
           } else {
             float v[3], pos[3], gq[4], mat[9];
-            qrot(v, xq, dm.geom_pos[g]);
+            qrot(v, xq, R.g_pos);
             for (int k = 0; k < 3; k++) pos[k] = S.xpos[b][k] + v[k];
-            const float dist0 = pos[2] - dm.ground_pos[2];
+            const float dist0 = pos[2] - gz;
             if (gt == CS_GEOM_SPHERE) {
-              const float r = dm.geom_size[g][0];
+              const float r = R.g_size[0];
               if (dist0 <= margin + r) {
                 float dist = dist0 - r;
                 cdst[0] = dist;
@@ -579,9 +632,9 @@ __global__ __launch_bounds__(64, 4) void env_kernel(KArgs A) {
                 cnt = 1;
               }
             } else if (gt == CS_GEOM_CYLINDER) {  // mjc_PlaneCylinder
-              qmul(gq, xq, dm.geom_quat[g]);
+              qmul(gq, xq, R.g_quat);
               q2m(mat, gq);
-              const float radius = dm.geom_size[g][0], half = dm.geom_size[g][1];
+              const float radius = R.g_size[0], half = R.g_size[1];
               float axis[3] = {mat[2], mat[5], mat[8]};
               float prjaxis = axis[2];
               if (prjaxis > 0.f) { axis[0] = -axis[0]; axis[1] = -axis[1]; axis[2] = -axis[2]; prjaxis = -prjaxis; }
@@ -622,11 +675,10 @@ __global__ __launch_bounds__(64, 4) void env_kernel(KArgs A) {
                 }
               }
             } else if (gt == CS_GEOM_BOX) {  // mjc_PlaneBox
-              qmul(gq, xq, dm.geom_quat[g]);
+              qmul(gq, xq, R.g_quat);
               q2m(mat, gq);
               for (int i = 0; i < 8 && cnt < 4; i++) {
-                float vx = (i & 1) ? dm.geom_size[g][0] : -dm.geom_size[g][0], vy = (i & 2) ? dm.geom_size[g][1] : -dm.geom_size[g][1],
-                      vz = (i & 4) ? dm.geom_size[g][2] : -dm.geom_size[g][2];
+                float vx = (i & 1) ? R.g_size[0] : -R.g_size[0], vy = (i & 2) ? R.g_size[1] : -R.g_size[1], vz = (i & 4) ? R.g_size[2] : -R.g_size[2];
                 float c[3] = {mat[0] * vx + mat[1] * vy + mat[2] * vz, mat[3] * vx + mat[4] * vy + mat[5] * vz, mat[6] * vx + mat[7] * vy + mat[8] * vz};
                 float ld = c[2];
                 if (dist0 + ld > margin || ld > 0.f) continue;
@@ -643,14 +695,14 @@ __global__ __launch_bounds__(64, 4) void env_kernel(KArgs A) {
 #pragma unroll
         for (int s = 0; s < 4; s++) {
           unsigned long long mk = __ballot(cnt > s);
-          off += __popcll(mk & lanemask_lt(lane));
+          off += __popcll(mk & lanemask_lt(ln));
           total += __popcll(mk);
         }
         for (int s = 0; s < cnt; s++) {
           int slot = off + s;
           if (slot < MC) {
             S.cdist[slot] = cdst[s];
-            S.cgeom[slot] = lane;
+            S.cgeom[slot] = ln;
             for (int k = 0; k < 3; k++) { S.cpos[slot][k] = cp[s][k]; S.cnrm[slot][k] = n[k]; }
           }
         }
@@ -660,41 +712,34 @@ __global__ __launch_bounds__(64, 4) void env_kernel(KArgs A) {
         while (mm) {
           const int g = __builtin_ctzll(mm);
           mm &= mm - 1;
-          const int b = dm.geom_body[g], adr = dm.geom_hulladr[g], num = dm.geom_hullnum[g];
+          const LaneRec& G = dm.rec[g];
+          const int b = G.g_body, adr = G.g_hulladr, num = G.g_hullnum;
           float xq[4] = {S.xquat[b][0], S.xquat[b][1], S.xquat[b][2], S.xquat[b][3]}, m[9];
           q2m(m, xq);
-          const float ln[3] = {m[6], m[7], m[8]};  // R^T n for n = +z
-          const float offz = S.xpos[b][2] - dm.ground_pos[2];
-          const float margin = dm.geom_margin[g];
+          const float lnz[3] = {m[6], m[7], m[8]};  // R^T n for n = +z
+          const float offz = S.xpos[b][2] - gz;
+          const float margin = G.g_margin;
           float best = 3.0e38f;
-          int besti = -1;
-          for (int i = lane; i < num; i += 64) {
+          int besti = 0x7fffffff;
+          for (int i = ln; i < num; i += 64) {
             const float* v = A.hull_vert + 3 * (adr + i);
-            float dist = offz + ln[0] * v[0] + ln[1] * v[1] + ln[2] * v[2];
+            float dist = offz + lnz[0] * v[0] + lnz[1] * v[1] + lnz[2] * v[2];
             if (dist < best) { best = dist; besti = i; }
           }
-          float bmin = wave_min(best);
-          unsigned long long who = __ballot(best == bmin && besti >= 0);
-          if (bmin > margin || who == 0ull) continue;
-          int src = __builtin_ctzll(who);
-          // lowest vertex index among ties, like a sequential scan
-          int bi = besti;
-          {
-            int cand = (best == bmin && besti >= 0) ? besti : 0x7fffffff;
+          const float bmin = wave_min(best);
+          if (!(bmin <= margin)) continue;
+          int bi = (best == bmin) ? besti : 0x7fffffff;  // lowest vertex index among ties, like a sequential scan
 #pragma unroll
-            for (int o = 32; o > 0; o >>= 1) cand = min(cand, __shfl_xor(cand, o, 64));
-            bi = cand;
-          }
-          (void)src;
+          for (int o = 32; o > 0; o >>= 1) bi = min(bi, __shfl_xor(bi, o, 64));
           int added = 0;
           for (int pass = 0; pass < 2; pass++) {
             const int lo = pass ? A.hull_adr[adr + bi] : 0, hi = pass ? A.hull_adr[adr + bi + 1] : 1;
             for (int e = lo; e < hi && added < 4; e++) {
               const int i = pass ? A.hull_nbr[e] : bi;
               const float* v = A.hull_vert + 3 * (adr + i);
-              float dist = offz + ln[0] * v[0] + ln[1] * v[1] + ln[2] * v[2];
+              float dist = offz + lnz[0] * v[0] + lnz[1] * v[1] + lnz[2] * v[2];
               if (dist > margin) continue;
-              if (ncon < MC && lane == 0) {
+              if (ncon < MC && ln == 0) {
                 float w[3] = {m[0] * v[0] + m[1] * v[1] + m[2] * v[2], m[3] * v[0] + m[4] * v[1] + m[5] * v[2], m[6] * v[0] + m[7] * v[1] + m[8] * v[2]};
                 S.cdist[ncon] = dist;
                 S.cgeom[ncon] = g;
@@ -709,166 +754,178 @@ __global__ __launch_bounds__(64, 4) void env_kernel(KArgs A) {
 
       // =========================================================== constraint rows (lane = row)
       const int ne = 3 * dm.neq, nf = dm.nfric;
-      // joint limits: compaction over bodies
       int nl = 0;
-      {
+      {  // joint limits: compaction over bodies
+        const LaneRec& R = dm.rec[ln];
         bool lo_v = false, hi_v = false;
         float dlo = 0.f, dhi = 0.f;
-        if (lane > 0 && lane < nbody && dm.body_jtype[lane] == CS_JNT_HINGE && dm.jnt_limited[lane]) {
-          float q = S.qpos[dm.body_qadr[lane]];
-          dlo = q - dm.jnt_range[lane][0];
-          dhi = dm.jnt_range[lane][1] - q;
-          lo_v = dlo < dm.jnt_margin[lane];
-          hi_v = dhi < dm.jnt_margin[lane];
+        if (ln > 0 && ln < nbody && R.b_jtype == CS_JNT_HINGE && R.j_limited) {
+          float q = S.qpos[R.b_qadr];
+          dlo = q - R.j_range[0];
+          dhi = R.j_range[1] - q;
+          lo_v = dlo < R.j_margin;
+          hi_v = dhi < R.j_margin;
         }
         unsigned long long ml = __ballot(lo_v), mh = __ballot(hi_v);
-        int rlo = __popcll(ml & lanemask_lt(lane)), rhi = __popcll(ml) + __popcll(mh & lanemask_lt(lane));
+        int rlo = __popcll(ml & lanemask_lt(ln)), rhi = __popcll(ml) + __popcll(mh & lanemask_lt(ln));
         nl = __popcll(ml) + __popcll(mh);
-        if (lo_v && rlo < MAXROW) { S.lim_body[rlo] = lane; S.lim_sign[rlo] = 1.f; S.lim_dist[rlo] = dlo; }
-        if (hi_v && rhi < MAXROW) { S.lim_body[rhi] = lane; S.lim_sign[rhi] = -1.f; S.lim_dist[rhi] = dhi; }
+        if (nl > L::NLIM) nl = L::NLIM;
+        if (lo_v && rlo < L::NLIM) { S.lim_body[rlo] = ln; S.lim_sign[rlo] = 1.f; S.lim_dist[rlo] = dlo; }
+        if (hi_v && rhi < L::NLIM) { S.lim_body[rhi] = ln; S.lim_sign[rhi] = -1.f; S.lim_dist[rhi] = dhi; }
       }
       {
         int room = (MAXROW - ne - nf - nl) / 4;
         if (room < 0) room = 0;
         if (ncon > room) ncon = room;
         if (ncon > MC) ncon = MC;
+        if (ne + 4 * ncon > NGENMAX) ncon = (NGENMAX - ne) / 4;
       }
       const int ngen = ne + 4 * ncon;       // general rows (dense J): equality + contact
       const int nefc = ngen + nf + nl;      // then unit rows: frictionloss, limits
       WSYNC();
 
       int rtype = RT_NONE, rdof = 0;
-      float rsign = 1.f, rpos = 0.f, rmargin = 0.f, rfloss = 0.f, rdiagA = 0.f, rmu = 0.f;
-      float rsolref[2] = {0.02f, 1.f}, rsolimp[5] = {0.9f, 0.95f, 0.001f, 0.5f, 2.f};
-      if (lane < ngen) {
-        float* Jr = S.J[lane];
-        for (int d = 0; d < NV; d++) Jr[d] = 0.f;
-        if (lane < ne) {
-          rtype = RT_EQ;
-          const int e = lane / 3, comp = lane - 3 * e;
-          const int b1 = dm.eq_body1[e], b2 = dm.eq_body2[e];
-          float dir[3] = {comp == 0 ? 1.f : 0.f, comp == 1 ? 1.f : 0.f, comp == 2 ? 1.f : 0.f};
-          float p1[3], p2[3], v[3], q1[4] = {S.xquat[b1][0], S.xquat[b1][1], S.xquat[b1][2], S.xquat[b1][3]},
-                                    q2[4] = {S.xquat[b2][0], S.xquat[b2][1], S.xquat[b2][2], S.xquat[b2][3]};
-          qrot(v, q1, dm.eq_anchor1[e]);
-          for (int k = 0; k < 3; k++) p1[k] = S.xpos[b1][k] + v[k];
-          qrot(v, q2, dm.eq_anchor2[e]);
-          for (int k = 0; k < 3; k++) p2[k] = S.xpos[b2][k] + v[k];
-          rpos = p1[comp] - p2[comp];
-          float off[3], od[3];
-          for (int k = 0; k < 3; k++) off[k] = p1[k] - com[k];
-          cross(od, off, dir);
-          for (int j = dm.body_lastdof[b1]; j >= 0; j = dm.dof_parent[j])
-            Jr[j] += dir[0] * S.cdof[j][3] + dir[1] * S.cdof[j][4] + dir[2] * S.cdof[j][5] + od[0] * S.cdof[j][0] + od[1] * S.cdof[j][1] + od[2] * S.cdof[j][2];
-          for (int k = 0; k < 3; k++) off[k] = p2[k] - com[k];
-          cross(od, off, dir);
-          for (int j = dm.body_lastdof[b2]; j >= 0; j = dm.dof_parent[j])
-            Jr[j] -= dir[0] * S.cdof[j][3] + dir[1] * S.cdof[j][4] + dir[2] * S.cdof[j][5] + od[0] * S.cdof[j][0] + od[1] * S.cdof[j][1] + od[2] * S.cdof[j][2];
-          rdiagA = S.p_binvw[b1] + S.p_binvw[b2];
-          for (int k = 0; k < 2; k++) rsolref[k] = dm.eq_solref[e][k];
-          for (int k = 0; k < 5; k++) rsolimp[k] = dm.eq_solimp[e][k];
-        } else {
-          rtype = RT_CONTACT;
-          const int c = (lane - ne) >> 2, edge = (lane - ne) & 3;
-          const int g = S.cgeom[c], b = dm.geom_body[g];
-          const float mu = S.p_gmu[g];
-          float nrm[3] = {S.cnrm[c][0], S.cnrm[c][1], S.cnrm[c][2]}, t1[3], t2[3];
-          make_frame(nrm, t1, t2);
-          const float* tk = (edge >> 1) ? t2 : t1;
-          const float sg = (edge & 1) ? -mu : mu;
-          float dir[3] = {nrm[0] + sg * tk[0], nrm[1] + sg * tk[1], nrm[2] + sg * tk[2]};
-          float off[3] = {S.cpos[c][0] - com[0], S.cpos[c][1] - com[1], S.cpos[c][2] - com[2]}, od[3];
-          cross(od, off, dir);
-          for (int j = dm.body_lastdof[b]; j >= 0; j = dm.dof_parent[j])
-            Jr[j] = dir[0] * S.cdof[j][3] + dir[1] * S.cdof[j][4] + dir[2] * S.cdof[j][5] + od[0] * S.cdof[j][0] + od[1] * S.cdof[j][1] + od[2] * S.cdof[j][2];
-          rpos = S.cdist[c];
-          rmargin = dm.geom_includemargin[g];
-          rmu = mu;
-          rdiagA = S.p_binvw[b] * (1.f + mu * mu);
-          for (int k = 0; k < 2; k++) rsolref[k] = dm.geom_solref[g][k];
-          for (int k = 0; k < 5; k++) rsolimp[k] = dm.geom_solimp[g][k];
+      float rsign = 1.f, rfloss = 0.f;
+      float rD = 0.f, rR = 1.f, raref = 0.f, rpos_dbg = 0.f;
+      {
+        float rpos = 0.f, rmargin = 0.f, rdiagA = 0.f, rmu = 0.f;
+        float rsolref[2] = {0.02f, 1.f}, rsolimp[5] = {0.9f, 0.95f, 0.001f, 0.5f, 2.f};
+        if (ln < ngen) {
+          float* Jr = S.J[ln];
+#pragma unroll
+          for (int d = 0; d < NV; d++) Jr[d] = 0.f;
+          if (ln < ne) {
+            rtype = RT_EQ;
+            const int e = ln / 3, comp = ln - 3 * e;
+            const LaneRec& E = dm.rec[e];
+            const int b1 = E.e_body1, b2 = E.e_body2;
+            float dir[3] = {comp == 0 ? 1.f : 0.f, comp == 1 ? 1.f : 0.f, comp == 2 ? 1.f : 0.f};
+            float p1[3], p2[3], v[3], q1[4] = {S.xquat[b1][0], S.xquat[b1][1], S.xquat[b1][2], S.xquat[b1][3]},
+                                      q2[4] = {S.xquat[b2][0], S.xquat[b2][1], S.xquat[b2][2], S.xquat[b2][3]};
+            qrot(v, q1, E.e_anchor1);
+            for (int k = 0; k < 3; k++) p1[k] = S.xpos[b1][k] + v[k];
+            qrot(v, q2, E.e_anchor2);
+            for (int k = 0; k < 3; k++) p2[k] = S.xpos[b2][k] + v[k];
+            rpos = p1[comp] - p2[comp];
+            float off[3], od[3];
+            for (int k = 0; k < 3; k++) off[k] = p1[k] - com[k];
+            cross(od, off, dir);
+            for (unsigned mk = dm.rec[b1].b_dofmask; mk; mk &= mk - 1) {
+              const int j = __builtin_ctz(mk);
+              Jr[j] += dir[0] * S.cdof[j][3] + dir[1] * S.cdof[j][4] + dir[2] * S.cdof[j][5] + od[0] * S.cdof[j][0] + od[1] * S.cdof[j][1] + od[2] * S.cdof[j][2];
+            }
+            for (int k = 0; k < 3; k++) off[k] = p2[k] - com[k];
+            cross(od, off, dir);
+            for (unsigned mk = dm.rec[b2].b_dofmask; mk; mk &= mk - 1) {
+              const int j = __builtin_ctz(mk);
+              Jr[j] -= dir[0] * S.cdof[j][3] + dir[1] * S.cdof[j][4] + dir[2] * S.cdof[j][5] + od[0] * S.cdof[j][0] + od[1] * S.cdof[j][1] + od[2] * S.cdof[j][2];
+            }
+            rdiagA = S.p_binvw[b1] + S.p_binvw[b2];
+            for (int k = 0; k < 2; k++) rsolref[k] = E.e_solref[k];
+            for (int k = 0; k < 5; k++) rsolimp[k] = E.e_solimp[k];
+          } else {
+            rtype = RT_CONTACT;
+            const int c = (ln - ne) >> 2, edge = (ln - ne) & 3;
+            const int g = S.cgeom[c];
+            const LaneRec& G = dm.rec[g];
+            const int b = G.g_body;
+            const float mu = S.p_gmu[g];
+            float nrm[3] = {S.cnrm[c][0], S.cnrm[c][1], S.cnrm[c][2]}, t1[3], t2[3];
+            make_frame(nrm, t1, t2);
+            const float* tk = (edge >> 1) ? t2 : t1;
+            const float sg = (edge & 1) ? -mu : mu;
+            float dir[3] = {nrm[0] + sg * tk[0], nrm[1] + sg * tk[1], nrm[2] + sg * tk[2]};
+            float off[3] = {S.cpos[c][0] - com[0], S.cpos[c][1] - com[1], S.cpos[c][2] - com[2]}, od[3];
+            cross(od, off, dir);
+            for (unsigned mk = dm.rec[b].b_dofmask; mk; mk &= mk - 1) {
+              const int j = __builtin_ctz(mk);
+              Jr[j] = dir[0] * S.cdof[j][3] + dir[1] * S.cdof[j][4] + dir[2] * S.cdof[j][5] + od[0] * S.cdof[j][0] + od[1] * S.cdof[j][1] + od[2] * S.cdof[j][2];
+            }
+            rpos = S.cdist[c];
+            rmargin = G.g_incmargin;
+            rmu = mu;
+            rdiagA = S.p_binvw[b] * (1.f + mu * mu);
+            for (int k = 0; k < 2; k++) rsolref[k] = G.g_solref[k];
+            for (int k = 0; k < 5; k++) rsolimp[k] = G.g_solimp[k];
+          }
+        } else if (ln < nefc) {
+          if (ln < ngen + nf) {
+            rtype = RT_FRIC;
+            rdof = dm.rec[ln - ngen].d_fric;  // model-level list; a per-env value of zero leaves the row inert
+            const LaneRec& D = dm.rec[rdof];
+            rfloss = S.p_floss[rdof];
+            rdiagA = S.p_dinvw[rdof];
+            for (int k = 0; k < 2; k++) rsolref[k] = D.d_solref[k];
+            for (int k = 0; k < 5; k++) rsolimp[k] = D.d_solimp[k];
+            if (!(rfloss > 0.f)) rtype = RT_NONE;
+          } else {
+            rtype = RT_LIMIT;
+            const int li = ln - ngen - nf;
+            const int b = S.lim_body[li];
+            const LaneRec& B = dm.rec[b];
+            rdof = B.b_dadr;
+            rsign = S.lim_sign[li];
+            rpos = S.lim_dist[li];
+            rmargin = B.j_margin;
+            rdiagA = S.p_dinvw[rdof];
+            for (int k = 0; k < 2; k++) rsolref[k] = B.j_solref[k];
+            for (int k = 0; k < 5; k++) rsolimp[k] = B.j_solimp[k];
+          }
         }
-      }
-      // (friction and limit rows are filled below, after the friction dof list is known)
-      if (lane >= ngen && lane < nefc) {
-        if (lane < ngen + nf) {
-          rtype = RT_FRIC;
-          rdof = dm.fric_dof[lane - ngen];  // model-level list; a per-env value of zero leaves the row inert
-          rfloss = S.p_floss[rdof];
-          rdiagA = S.p_dinvw[rdof];
-          for (int k = 0; k < 2; k++) rsolref[k] = dm.dof_solref[rdof][k];
-          for (int k = 0; k < 5; k++) rsolimp[k] = dm.dof_solimp[rdof][k];
-          if (!(rfloss > 0.f)) rtype = RT_NONE;
-        } else {
-          rtype = RT_LIMIT;
-          const int li = lane - ngen - nf;
-          const int b = S.lim_body[li];
-          rdof = dm.body_dadr[b];
-          rsign = S.lim_sign[li];
-          rpos = S.lim_dist[li];
-          rmargin = dm.jnt_margin[b];
-          rdiagA = S.p_dinvw[rdof];
-          for (int k = 0; k < 2; k++) rsolref[k] = dm.jnt_solref[b][k];
-          for (int k = 0; k < 5; k++) rsolimp[k] = dm.jnt_solimp[b][k];
+        // KBIP, R, D, aref
+        if (rtype != RT_NONE) {
+          float imp = impedance(rsolimp, rpos, rmargin);
+          float dmax = fminf(MAXIMP, fmaxf(MINIMP, rsolimp[1]));
+          float K, B;
+          if (rsolref[0] > 0.f) {
+            float tc = fmaxf(rsolref[0], 2.f * h), dr = rsolref[1];
+            K = 1.f / fmaxf(MINVAL, dmax * dmax * tc * tc * dr * dr);
+            B = 2.f / fmaxf(MINVAL, dmax * tc);
+          } else { K = -rsolref[0] / fmaxf(MINVAL, dmax * dmax); B = -rsolref[1] / fmaxf(MINVAL, dmax); }
+          if (rtype == RT_FRIC) K = 0.f;
+          rR = fmaxf(MINVAL, (1.f - imp) * rdiagA / imp);
+          if (rtype == RT_CONTACT) { float mu = rmu * rsqrtf(fmaxf(MINVAL, dm.impratio)); rR = 2.f * mu * mu * rR; }
+          rD = 1.f / rR;
+          float vel;
+          if (rtype == RT_EQ || rtype == RT_CONTACT) {
+            vel = 0.f;
+            const float* Jr = S.J[ln];
+#pragma unroll
+            for (int d = 0; d < NV; d++) vel += Jr[d] * S.qvel[d];
+          } else vel = rsign * S.qvel[rdof];
+          raref = -B * vel - K * imp * (rpos - rmargin);
         }
+        rpos_dbg = rpos;
       }
-      // KBIP, R, D, aref
-      float rD = 0.f, rR = 1.f, raref = 0.f;
-      if (rtype != RT_NONE) {
-        float imp = impedance(rsolimp, rpos, rmargin);
-        float dmax = fminf(MAXIMP, fmaxf(MINIMP, rsolimp[1]));
-        float K, B;
-        if (rsolref[0] > 0.f) {
-          float tc = fmaxf(rsolref[0], 2.f * h), dr = rsolref[1];
-          K = 1.f / fmaxf(MINVAL, dmax * dmax * tc * tc * dr * dr);
-          B = 2.f / fmaxf(MINVAL, dmax * tc);
-        } else { K = -rsolref[0] / fmaxf(MINVAL, dmax * dmax); B = -rsolref[1] / fmaxf(MINVAL, dmax); }
-        if (rtype == RT_FRIC) K = 0.f;
-        rR = fmaxf(MINVAL, (1.f - imp) * rdiagA / imp);
-        if (rtype == RT_CONTACT) { float mu = rmu * rsqrtf(fmaxf(MINVAL, dm.impratio)); rR = 2.f * mu * mu * rR; }
-        rD = 1.f / rR;
-        float vel;
-        if (rtype == RT_EQ || rtype == RT_CONTACT) {
-          vel = 0.f;
-          const float* Jr = S.J[lane];
-          for (int d = 0; d < NV; d++) vel += Jr[d] * S.qvel[d];
-        } else vel = (rtype == RT_LIMIT ? rsign : 1.f) * S.qvel[rdof];
-        raref = -B * vel - K * imp * (rpos - rmargin);
-      }
-      if (rtype == RT_FRIC) rsign = 1.f;
+      const bool dense_row = rtype == RT_EQ || rtype == RT_CONTACT;
+      const bool unit_row = rtype == RT_FRIC || rtype == RT_LIMIT;
       WSYNC();
 
       // =========================================================== Newton solver (mj_solNewton), warm-started from qacc
       float Jaref = 0.f, Jv = 0.f, Ma = 0.f;
-      float a_row[NV];
       float dinv = 1.f;
-      int e_idx[EPL], e_a[EPL], e_b[EPL];
-#pragma unroll
-      for (int t = 0; t < EPL; t++) {
-        int e = lane + 64 * t;
-        e_idx[t] = e < TRI ? e : -1;
-        e_a[t] = e < TRI ? dm.tri_row[e] : 0;
-        e_b[t] = e < TRI ? dm.tri_col[e] : 0;
-      }
       auto mulM = [&](const float* v) -> float {  // (M v)[lane]
         float s = 0.f;
-        if (lane < NV)
-          for (int k = 0; k < NV; k++) s += S.M[tri_idx(lane, k)] * v[k];
+        if (ln < NV) {
+          const float* Mr = S.M[ln];
+#pragma unroll
+          for (int k = 0; k < NV; k++) s += Mr[k] * v[k];
+        }
         return s;
       };
       auto rowdot = [&](const float* v) -> float {  // J[row] . v for this lane's row
         float s = 0.f;
-        if (rtype == RT_EQ || rtype == RT_CONTACT) {
-          const float* Jr = S.J[lane];
+        if (dense_row) {
+          const float* Jr = S.J[ln];
+#pragma unroll
           for (int d = 0; d < NV; d++) s += Jr[d] * v[d];
-        } else if (rtype != RT_NONE) s = rsign * v[rdof];
+        } else if (unit_row) s = rsign * v[rdof];
         return s;
       };
-      Jaref = rowdot(S.qacc) - raref;
-      if (rtype == RT_NONE) Jaref = 0.f;
+      Jaref = rtype == RT_NONE ? 0.f : rowdot(S.qacc) - raref;
       Ma = mulM(S.qacc);
-      float qacc_l = lane < NV ? S.qacc[lane] : 0.f;
-      const float qsm_l = lane < NV ? S.qsm[lane] : 0.f;
+      float qacc_l = ln < NV ? S.qacc[ln] : 0.f;
+      const float qsm_l = ln < NV ? S.qsm[ln] : 0.f;
       float cost = 0.f, gauss = 0.f, grad_l = 0.f;
       const float scale = 1.f / (meaninertia * (float)(NV > 1 ? NV : 1));
       int niter = 0;
@@ -886,56 +943,60 @@ __global__ __launch_bounds__(64, 4) void env_kernel(KArgs A) {
         } else if (rtype == RT_LIMIT || rtype == RT_CONTACT) {
           if (Jaref < 0.f) { f = -rD * Jaref; c = 0.5f * rD * Jaref * Jaref; dact = rD; }
         }
-        S.rowf[lane] = f;
-        S.rowD[lane] = dact;
-        if (lane < NV) { S.dofD[lane] = 0.f; S.qcon[lane] = 0.f; }
+        S.w.r.rowf[ln] = f;
+        S.w.r.rowD[ln] = dact;
+        if (ln < NV) { S.dofD[ln] = 0.f; S.qcon[ln] = 0.f; }
         WSYNC();
-        if (rtype == RT_FRIC || rtype == RT_LIMIT) {
+        if (unit_row) {
           atomicAdd(&S.dofD[rdof], dact);
           atomicAdd(&S.qcon[rdof], rsign * f);
         }
         WSYNC();
         float qc = 0.f;
-        if (lane < NV) {
-          qc = S.qcon[lane];
-          for (int r = 0; r < ngen; r++) qc += S.J[r][lane] * S.rowf[r];
-          S.qcon[lane] = qc;
+        if (ln < NV) {
+          qc = S.qcon[ln];
+          for (int r = 0; r < ngen; r++) qc += S.J[r][ln] * S.w.r.rowf[r];
+          S.qcon[ln] = qc;
         }
-        gauss = wave_sum(lane < NV ? (0.5f * Ma - qsm_l) * qacc_l : 0.f);
+        gauss = wave_sum(ln < NV ? (0.5f * Ma - qsm_l) * qacc_l : 0.f);
         cost = wave_sum(c) + gauss;
-        grad_l = lane < NV ? Ma - qsm_l - qc : 0.f;
+        grad_l = ln < NV ? Ma - qsm_l - qc : 0.f;
       };
 
       auto update_search = [&]() {
-        // Hessian H = M + J^T diag(D_active) J, entry-parallel over the packed lower triangle
-        float hacc[EPL];
+        // Hessian H = M + J^T diag(D_active) J, entry-parallel over the lower triangle, mirrored into a full square
+        {
+          int ea[EPL], eb[EPL];
+          float hacc[EPL];
 #pragma unroll
-        for (int t = 0; t < EPL; t++) hacc[t] = e_idx[t] >= 0 ? S.M[e_idx[t]] : 0.f;
-        for (int r = 0; r < ngen; r++) {
-          float dr = rfl(S.rowD[r]);
-          if (dr == 0.f) continue;
-          const float* Jr = S.J[r];
+          for (int t = 0; t < EPL; t++) {
+            const int e = ln + 64 * t;
+            ea[t] = e < TRI ? dm.tri_row[e] : 0;
+            eb[t] = e < TRI ? dm.tri_col[e] : 0;
+            hacc[t] = S.M[ea[t]][eb[t]];
+          }
+          for (int r = 0; r < ngen; r++) {
+            const float dr = rfl(S.w.r.rowD[r]);
+            if (dr == 0.f) continue;
+            const float* Jr = S.J[r];
 #pragma unroll
-          for (int t = 0; t < EPL; t++) hacc[t] += dr * Jr[e_a[t]] * Jr[e_b[t]];
+            for (int t = 0; t < EPL; t++) hacc[t] += dr * Jr[ea[t]] * Jr[eb[t]];
+          }
+#pragma unroll
+          for (int t = 0; t < EPL; t++)
+            if (ln + 64 * t < TRI) { S.u.H[ea[t]][eb[t]] = hacc[t]; S.u.H[eb[t]][ea[t]] = hacc[t]; }
         }
-#pragma unroll
-        for (int t = 0; t < EPL; t++)
-          if (e_idx[t] >= 0) S.H[e_idx[t]] = hacc[t];
         WSYNC();
-        if (lane < NV) {
+        float a_row[NV];
+        {
+          const float* Hr = S.u.H[ln < NV ? ln : 0];
+          const float dd = ln < NV ? S.dofD[ln] : 0.f;  // unit rows (frictionloss, limits) only touch the diagonal
 #pragma unroll
-          for (int k = 0; k < NV; k++) a_row[k] = S.H[tri_idx(lane, k)];
-        } else {
-#pragma unroll
-          for (int k = 0; k < NV; k++) a_row[k] = 0.f;
+          for (int k = 0; k < NV; k++) a_row[k] = (ln < NV ? Hr[k] : 0.f) + ((ln == k) ? dd : 0.f);
         }
-        // unit rows (frictionloss, limits) only touch the diagonal
-        float dd = lane < NV ? S.dofD[lane] : 0.f;
-#pragma unroll
-        for (int k = 0; k < NV; k++) a_row[k] += (lane == k) ? dd : 0.f;
-        chol_regs<NV>(a_row, dinv, lane);
-        float mg = chol_solve_regs<NV>(a_row, dinv, grad_l, lane);
-        if (lane < NV) S.sr[lane] = -mg;
+        chol_regs<NV>(a_row, dinv, ln);
+        const float mg = chol_solve_regs<NV>(a_row, dinv, grad_l, ln);
+        if (ln < NV) S.sr[ln] = -mg;
         WSYNC();
       };
 
@@ -944,19 +1005,20 @@ __global__ __launch_bounds__(64, 4) void env_kernel(KArgs A) {
       if (A.mode == MODE_DEBUG && A.dbg != nullptr) {
         // dump position/velocity-stage intermediates before the solve
         float* D = A.dbg;
-        if (lane == 0) { D[0] = (float)ncon; D[1] = (float)nefc; D[2] = (float)ne; D[3] = (float)nf; D[4] = (float)nl; D[5] = cost; D[6] = gradnorm; D[7] = (float)ngen; }
-        if (lane < nbody) { for (int k = 0; k < 3; k++) D[64 + lane * 3 + k] = S.xpos[lane][k]; for (int k = 0; k < 4; k++) D[192 + lane * 4 + k] = S.xquat[lane][k]; }
-        for (int e = lane; e < TRI; e += 64) D[512 + e] = S.M[e];
-        if (lane < NV) { D[1100 + lane] = S.qsm[lane]; D[1140 + lane] = S.qbias[lane]; for (int q = 0; q < 6; q++) D[1200 + lane * 6 + q] = S.cdof[lane][q]; }
-        D[1400 + lane] = (float)rtype; D[1464 + lane] = rD; D[1528 + lane] = raref; D[1592 + lane] = rpos; D[1656 + lane] = Jaref;
-        if (lane < ngen) for (int d = 0; d < NV; d++) D[2048 + lane * NV + d] = S.J[lane][d];
-        if (lane < MC) { D[1720 + lane] = lane < ncon ? S.cdist[lane] : 0.f; for (int k = 0; k < 3; k++) D[1740 + lane * 3 + k] = lane < ncon ? S.cpos[lane][k] : 0.f; }
+        if (ln == 0) { D[0] = (float)ncon; D[1] = (float)nefc; D[2] = (float)ne; D[3] = (float)nf; D[4] = (float)nl; D[5] = cost; D[6] = gradnorm; D[7] = (float)ngen; }
+        if (ln < nbody) { for (int k = 0; k < 3; k++) D[64 + ln * 3 + k] = S.xpos[ln][k]; for (int k = 0; k < 4; k++) D[192 + ln * 4 + k] = S.xquat[ln][k]; }
+        for (int e = ln; e < TRI; e += 64) D[512 + e] = S.M[dm.tri_row[e]][dm.tri_col[e]];
+        if (ln < NV) { D[1100 + ln] = S.qsm[ln]; for (int q = 0; q < 6; q++) D[1200 + ln * 6 + q] = S.cdof[ln][q]; }
+        D[1400 + ln] = (float)rtype; D[1464 + ln] = rD; D[1528 + ln] = raref; D[1592 + ln] = rpos_dbg; D[1656 + ln] = Jaref;
+        if (ln < ngen) for (int d = 0; d < NV; d++) D[2048 + ln * NV + d] = S.J[ln][d];
+        if (ln < MC) { D[1720 + ln] = ln < ncon ? S.cdist[ln] : 0.f; for (int k = 0; k < 3; k++) D[1740 + ln * 3 + k] = ln < ncon ? S.cpos[ln][k] : 0.f; }
       }
+#pragma nounroll
       while (niter < maxiter) {
         if (scale * gradnorm < A.tol32) break;
         update_search();
         // ---- exact line search on the piecewise-quadratic cost (PrimalSearch)
-        const float sr_l = lane < NV ? S.sr[lane] : 0.f;
+        const float sr_l = ln < NV ? S.sr[ln] : 0.f;
         const float Mv = mulM(S.sr);
         Jv = rowdot(S.sr);
         const float snorm = sqrtf(wave_sum(sr_l * sr_l));
@@ -998,6 +1060,7 @@ __global__ __launch_bounds__(64, 4) void env_kernel(KArgs A) {
             const float dir = p1.d0 < 0.f ? 1.f : -1.f;
             Pnt p2 = p1;
             bool p2update = false;
+#pragma nounroll
             while (p1.d0 * dir <= -gtol && lsit < maxls) {
               p2 = p1; p2update = true;
               p1 = eval(p1.alpha - p1.d0 / p1.d1); lsit++;
@@ -1009,25 +1072,28 @@ __global__ __launch_bounds__(64, 4) void env_kernel(KArgs A) {
             if (!done) {
               Pnt p2next = p1;
               Pnt p1next = eval(p1.alpha - p1.d0 / p1.d1); lsit++;
+#pragma nounroll
               while (lsit < maxls) {
                 Pnt pmid = eval(0.5f * (p1.alpha + p2.alpha)); lsit++;
-                Pnt cand[3] = {p1next, p2next, pmid};
-                int best = -1;
-                float bestcost = 0.f;
-                for (int i = 0; i < 3; i++)
-                  if (fabsf(cand[i].d0) < gtol && (best == -1 || cand[i].cost < bestcost)) { best = i; bestcost = cand[i].cost; }
-                if (best >= 0) { alpha = cand[best].alpha; done = true; break; }
+                // candidates: p1next, p2next, pmid (kept as named values: no dynamically indexed array -> no scratch)
+                {
+                  bool found = false;
+                  float bestcost = 0.f, besta = 0.f;
+                  if (fabsf(p1next.d0) < gtol) { found = true; bestcost = p1next.cost; besta = p1next.alpha; }
+                  if (fabsf(p2next.d0) < gtol && (!found || p2next.cost < bestcost)) { found = true; bestcost = p2next.cost; besta = p2next.alpha; }
+                  if (fabsf(pmid.d0) < gtol && (!found || pmid.cost < bestcost)) { found = true; bestcost = pmid.cost; besta = pmid.alpha; }
+                  if (found) { alpha = besta; done = true; break; }
+                }
                 int b1 = 0, b2 = 0;
-                for (int i = 0; i < 3; i++) {
-                  if (p1.d0 < 0.f && cand[i].d0 < 0.f && p1.d0 < cand[i].d0) { p1 = cand[i]; b1 = 1; }
-                  else if (p1.d0 > 0.f && cand[i].d0 > 0.f && p1.d0 > cand[i].d0) { p1 = cand[i]; b1 = 2; }
-                }
+                const Pnt c0_ = p1next, c1_ = p2next, c2_ = pmid;
+#define BRACKET_UPDATE(P, C, FLAG)                                                                   \
+  if (P.d0 < 0.f && C.d0 < 0.f && P.d0 < C.d0) { P = C; FLAG = 1; }                                    \
+  else if (P.d0 > 0.f && C.d0 > 0.f && P.d0 > C.d0) { P = C; FLAG = 2; }
+                BRACKET_UPDATE(p1, c0_, b1) BRACKET_UPDATE(p1, c1_, b1) BRACKET_UPDATE(p1, c2_, b1)
                 if (b1) { p1next = eval(p1.alpha - p1.d0 / p1.d1); lsit++; }
-                for (int i = 0; i < 3; i++) {
-                  if (p2.d0 < 0.f && cand[i].d0 < 0.f && p2.d0 < cand[i].d0) { p2 = cand[i]; b2 = 1; }
-                  else if (p2.d0 > 0.f && cand[i].d0 > 0.f && p2.d0 > cand[i].d0) { p2 = cand[i]; b2 = 2; }
-                }
+                BRACKET_UPDATE(p2, c0_, b2) BRACKET_UPDATE(p2, c1_, b2) BRACKET_UPDATE(p2, c2_, b2)
                 if (b2) { p2next = eval(p2.alpha - p2.d0 / p2.d1); lsit++; }
+#undef BRACKET_UPDATE
                 if (!b1 && !b2) { alpha = pmid.alpha; done = true; break; }
               }
               if (!done) {
@@ -1044,7 +1110,7 @@ __global__ __launch_bounds__(64, 4) void env_kernel(KArgs A) {
         qacc_l += alpha * sr_l;
         Ma += alpha * Mv;
         Jaref += alpha * Jv;
-        if (lane < NV) S.qacc[lane] = qacc_l;
+        if (ln < NV) S.qacc[ln] = qacc_l;
         const float oldcost = cost;
         update_constraint();
         gradnorm = sqrtf(wave_sum(grad_l * grad_l));
@@ -1054,40 +1120,35 @@ __global__ __launch_bounds__(64, 4) void env_kernel(KArgs A) {
       }
       if (A.mode == MODE_DEBUG && A.dbg != nullptr) {
         float* D = A.dbg;
-        if (lane == 0) { D[8] = (float)niter; D[9] = cost; D[10] = gradnorm; }
-        if (lane < NV) { D[1000 + lane] = qacc_l; D[1040 + lane] = S.qcon[lane]; }
-        D[1800 + lane] = S.rowf[lane];
-        if (lane < 4) D[16 + lane] = s_quat[lane];
-        if (lane < 3) { D[20 + lane] = s_gyro[lane]; D[24 + lane] = s_vel[lane]; }
+        if (ln == 0) { D[8] = (float)niter; D[9] = cost; D[10] = gradnorm; }
+        if (ln < NV) { D[1000 + ln] = qacc_l; D[1040 + ln] = S.qcon[ln]; }
+        D[1800 + ln] = S.w.r.rowf[ln];
+        if (ln < 4) D[16 + ln] = s_quat[ln];
+        if (ln < 3) { D[20 + ln] = s_gyro[ln]; D[24 + ln] = s_vel[ln]; }
       }
 
       // =========================================================== mj_implicit (implicitfast) + mj_advance
       {
-        if (lane < NV) {
+        float a_row[NV];
+        {
+          const float* Mr = S.M[ln < NV ? ln : 0];
+          const float hd = ln < NV ? h * dm.rec[ln].d_damping : 0.f;
 #pragma unroll
-          for (int k = 0; k < NV; k++) a_row[k] = S.M[tri_idx(lane, k)];
-        } else {
-#pragma unroll
-          for (int k = 0; k < NV; k++) a_row[k] = 0.f;
+          for (int k = 0; k < NV; k++) a_row[k] = (ln < NV ? Mr[k] : 0.f) + ((ln == k) ? hd : 0.f);
         }
-        const float hd = lane < NV ? h * dm.dof_damping[lane] : 0.f;
-#pragma unroll
-        for (int k = 0; k < NV; k++) a_row[k] += (lane == k) ? hd : 0.f;
-        chol_regs<NV>(a_row, dinv, lane);
-        const float rhs = lane < NV ? qsm_l + S.qcon[lane] : 0.f;
-        const float qa = chol_solve_regs<NV>(a_row, dinv, rhs, lane);
+        chol_regs<NV>(a_row, dinv, ln);
+        const float rhs = ln < NV ? qsm_l + S.qcon[ln] : 0.f;
+        const float qa = chol_solve_regs<NV>(a_row, dinv, rhs, ln);
         WSYNC();
         if (A.mode != MODE_DEBUG) {
-          if (lane < NV) {
-            qv += h * qa;
-            S.qvel[lane] = qv;
-          }
+          if (ln < NV) S.qvel[ln] = qv + h * qa;
           WSYNC();
-          if (lane > 0 && lane < nbody) {
-            const int jt = dm.body_jtype[lane];
-            if (jt == CS_JNT_HINGE) S.qpos[dm.body_qadr[lane]] += h * S.qvel[dm.body_dadr[lane]];
+          if (ln > 0 && ln < nbody) {
+            const LaneRec& R = dm.rec[ln];
+            const int jt = R.b_jtype;
+            if (jt == CS_JNT_HINGE) S.qpos[R.b_qadr] += h * S.qvel[R.b_dadr];
             else if (jt == CS_JNT_FREE) {
-              const int qa0 = dm.body_qadr[lane], da = dm.body_dadr[lane];
+              const int qa0 = R.b_qadr, da = R.b_dadr;
               for (int k = 0; k < 3; k++) S.qpos[qa0 + k] += h * S.qvel[da + k];
               float w[3] = {S.qvel[da + 3], S.qvel[da + 4], S.qvel[da + 5]};
               float wn = sqrtf(dot3(w, w));
@@ -1105,7 +1166,7 @@ __global__ __launch_bounds__(64, 4) void env_kernel(KArgs A) {
           // qacc (the solver's) stays in S.qacc as next substep's warm start
           WSYNC();
         } else if (A.dbg != nullptr) {
-          if (lane < NV) A.dbg[1080 + lane] = qa;
+          if (ln < NV) A.dbg[1080 + ln] = qa;
         }
       }
     }  // substeps
@@ -1115,12 +1176,11 @@ __global__ __launch_bounds__(64, 4) void env_kernel(KArgs A) {
     {
       bool nf_ = false;
       if (lane < nq) nf_ = !(fabsf(S.qpos[lane]) < 1e10f);
-      if (lane < nv) nf_ = nf_ || !(fabsf(S.qvel[lane]) < 1e10f) || !(fabsf(S.qacc[lane]) < 1e10f);
+      if (lane < NV) nf_ = nf_ || !(fabsf(S.qvel[lane]) < 1e10f) || !(fabsf(S.qacc[lane]) < 1e10f);
       bad = __ballot(nf_) != 0ull;
     }
     if (sim_step == ob.max_sim_step) truncated = 1;
     if (bad) terminated = 1;
-    // (term_mode 1: cfrc_ext test, flamingo_p_v3 — evaluated by the caller of a later round)
     do_reset = bad || ((terminated || truncated) && ob.auto_reset);
   }
 
@@ -1128,19 +1188,14 @@ __global__ __launch_bounds__(64, 4) void env_kernel(KArgs A) {
   int nan_resets = meta[4];
   if (bad) nan_resets++;
   if (do_reset) {
-    if (lane < nq) S.qpos[lane] = dm.init_qpos[lane];
-    if (lane < nv) { S.qvel[lane] = 0.f; S.qacc[lane] = 0.f; }
+    if (lane < nq) S.qpos[lane] = dm.rec[lane].init_qpos;
+    if (lane < NV) { S.qvel[lane] = 0.f; S.qacc[lane] = 0.f; }
     WSYNC();
-    if (lane < dm.init_noise_nq) {
-      unsigned rnd[4];
-      philox(k0, k1, step_count, 2u, (unsigned)lane, 0u, rnd);
-      S.qpos[dm.init_noise_qadr[lane]] += ob.init_noise * (2.f * u01(rnd[0]) - 1.f);
-    }
+    if (lane < dm.init_noise_nq)
+      S.qpos[dm.rec[lane].n_qadr] += ob.init_noise * (2.f * u01(philox_first(k0, k1, step_count, 2u, (unsigned)lane, 0u)) - 1.f);
     WSYNC();
     // sensors of the mj_forward at the reset state: zero velocity, IMU orientation from the base quaternion
     {
-      const int ib = dm.imu_body;
-      (void)ib;
       float xq[4] = {S.qpos[3], S.qpos[4], S.qpos[5], S.qpos[6]};
       qnorm(xq);
       qmul(s_quat, xq, dm.imu_quat);
@@ -1161,7 +1216,6 @@ __global__ __launch_bounds__(64, 4) void env_kernel(KArgs A) {
     const float pg[3] = {-m[6], -m[7], -m[8]};  // R^T (0,0,-1)
     const bool fill = do_reset;                 // reset fills every stack row with the first frame
     if (lane < nu) S.act[lane] = raw_action;
-    if (lane < CS_MAXCMD) S.cmd[lane] = applied_cmd;
     WSYNC();
     float* so = A.state_out + (size_t)env * ob.state_dim;
     const int sd = ob.stacked_dim, S_ = ob.stack_size;
@@ -1169,21 +1223,19 @@ __global__ __launch_bounds__(64, 4) void env_kernel(KArgs A) {
       const int f = ob.el_field[e], idx = ob.el_index[e];
       float val = 0.f;
       switch (f) {
-        case CS_OBS_DOF_POS: val = S.qpos[dm.obs_qadr[idx]] * dm.obs_qgear[idx]; break;
-        case CS_OBS_DOF_VEL: val = S.qvel[dm.obs_dadr[idx]] * dm.obs_dgear[idx]; break;
-        case CS_OBS_ANG_VEL: val = s_gyro[idx]; break;
-        case CS_OBS_LIN_VEL: val = s_vel[idx]; break;
-        case CS_OBS_PROJ_GRAVITY: val = pg[idx]; break;
+        case CS_OBS_DOF_POS: val = S.qpos[dm.rec[idx].o_qadr] * dm.rec[idx].o_qgear; break;
+        case CS_OBS_DOF_VEL: val = S.qvel[dm.rec[idx].o_dadr] * dm.rec[idx].o_dgear; break;
+        case CS_OBS_ANG_VEL: val = idx == 0 ? s_gyro[0] : (idx == 1 ? s_gyro[1] : s_gyro[2]); break;
+        case CS_OBS_LIN_VEL: val = idx == 0 ? s_vel[0] : (idx == 1 ? s_vel[1] : s_vel[2]); break;
+        case CS_OBS_PROJ_GRAVITY: val = idx == 0 ? pg[0] : (idx == 1 ? pg[1] : pg[2]); break;
         case CS_OBS_LAST_ACTION: val = S.act[idx]; break;
         default: val = 0.f; break;
       }
       if (ob.noise_enabled && f != CS_OBS_LAST_ACTION && f != CS_OBS_COMMAND) {
         // truncated Gaussian by inverse CDF (scipy.stats.truncnorm.rvs, noise_generator_utils.py:22-28)
-        unsigned rnd[4];
-        philox(k0, k1, step_count, 1u, (unsigned)e, 0u, rnd);
         const float mean = ob.noise_mean[f], sd_ = ob.noise_std[f];
         const float ca = normcdff((ob.noise_lower[f] - mean) / sd_), cb = normcdff((ob.noise_upper[f] - mean) / sd_);
-        float z = normcdfinvf(ca + u01(rnd[0]) * (cb - ca));
+        float z = normcdfinvf(ca + u01(philox_first(k0, k1, step_count, 1u, (unsigned)e, 0u)) * (cb - ca));
         float nz = fminf(ob.noise_upper[f], fmaxf(ob.noise_lower[f], mean + sd_ * z));
         val += nz;
       }
@@ -1194,17 +1246,18 @@ __global__ __launch_bounds__(64, 4) void env_kernel(KArgs A) {
       else if (sim_step == 0 || (sim_step % interval) == 0) { vs = val * ob.el_scale[e]; *cache = vs; }
       else vs = *cache;
       const bool is_cmd = f == CS_OBS_COMMAND;
+      const float cmdv = is_cmd ? S.cmd[idx] : 0.f;
       if (e < sd) {
         float* st = rec + lay.s_stack;
         for (int k = S_ - 1; k >= 1; k--) {
           float o = fill ? vs : st[(k - 1) * sd + e];
           st[k * sd + e] = o;
-          so[k * sd + e] = is_cmd ? S.cmd[idx] : o;
+          so[k * sd + e] = is_cmd ? cmdv : o;
         }
         st[e] = vs;
-        so[e] = is_cmd ? S.cmd[idx] : vs;
+        so[e] = is_cmd ? cmdv : vs;
       } else {
-        so[S_ * sd + (e - sd)] = is_cmd ? S.cmd[idx] : vs;
+        so[S_ * sd + (e - sd)] = is_cmd ? cmdv : vs;
       }
     }
   }
@@ -1216,14 +1269,16 @@ __global__ __launch_bounds__(64, 4) void env_kernel(KArgs A) {
       float dsq = lane < nu ? (raw_action - prev_action) * (raw_action - prev_action) : 0.f;
       float rmse = sqrtf(wave_sum(dsq) / (float)nu);
       if (lane == 0) { inf[0] = rmse; inf[1] = s_vel[0]; inf[2] = s_vel[1]; inf[3] = s_gyro[2]; }
-      if (lane < nu) { inf[4 + lane] = tq_lane; inf[4 + nu + lane] = raw_action * dm.ctl_scale[lane]; }
-      if (lane < dm.ninfo_state)
-        inf[4 + 2 * nu + lane] = (dm.info_kind[lane] == 0 ? S.qpos[dm.info_adr[lane]] : S.qvel[dm.info_adr[lane]]) * dm.info_gear[lane];
+      if (lane < nu) { inf[4 + lane] = tq_lane; inf[4 + nu + lane] = raw_action * dm.rec[lane].a_scale; }
+      if (lane < dm.ninfo_state) {
+        const LaneRec& R = dm.rec[lane];
+        inf[4 + 2 * nu + lane] = (R.i_kind == 0 ? S.qpos[R.i_adr] : S.qvel[R.i_adr]) * R.i_gear;
+      }
     }
     if (lane == 0) { A.terminated[env] = (uint8_t)terminated; A.truncated[env] = (uint8_t)truncated; }
   }
   if (lane < nq) rec[lay.s_qpos + lane] = S.qpos[lane];
-  if (lane < nv) { rec[lay.s_qvel + lane] = S.qvel[lane]; rec[lay.s_warm + lane] = S.qacc[lane]; }
+  if (lane < NV) { rec[lay.s_qvel + lane] = S.qvel[lane]; rec[lay.s_warm + lane] = S.qacc[lane]; }
   if (lane < nu) rec[lay.s_lastact + lane] = do_reset ? 0.f : raw_action;
   if (lane == 0) { meta[0] = sim_step; meta[1] = (int)(step_count + 1u); meta[2] = has_prev; meta[4] = nan_resets; }
 }
