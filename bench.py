@@ -134,6 +134,8 @@ def main():
     kernel_ms, launches = env.engine.kernel_time()
     env.engine.set_timing(False)
     finite = bool(torch.isfinite(state).all().item())
+    st = env.solver_stats()
+    nsub = max(1, (st["step_count"] - n) * 4)    # the reset launch also bumps the step counter once per env
 
     tmax = torch.tensor([dt], dtype=torch.float64, device=env.device)
     if world > 1:
@@ -151,7 +153,10 @@ def main():
             "config": {"workload": f"{ROBOT} x {n} envs per GPU, flat terrain, precision medium (4 x 5 ms substeps), "
                                    "GUI-default domain randomisation + sensor noise low, sinusoid actions, auto-reset",
                        "envs_per_gpu": n, "global_envs": world * n, "substeps_per_s": value * 4, "parallelism": f"shard{world}",
-                       "finite": finite, "fleet_action_diff_RMSE": fleet["action_diff_RMSE"]["mean"]},
+                       "finite": finite, "fleet_action_diff_RMSE": fleet["action_diff_RMSE"]["mean"],
+                       "solver_per_substep": {"rows": st["rows"] / nsub, "newton_iters": st["newton_iters"] / nsub,
+                                              "ls_evals": st["ls_evals"] / nsub, "factorisations": st["factorisations"] / nsub},
+                       "nan_resets": st["nan_resets"]},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "kernel": "cosim::env_kernel<18,14>", "kernel_ms": kernel_ms, "launches": launches,

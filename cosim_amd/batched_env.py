@@ -233,6 +233,17 @@ class BatchedEnv:
                 self.engine.set(name, x.data_ptr(), self._stream())
                 t.cuda.synchronize(self.device)
 
+    def solver_stats(self):
+        """Cumulative solver counters since creation (fleet sums): control steps, constraint rows (summed over
+        substeps), Newton iterations, line-search evaluations, Hessian factorisations, non-finite resets."""
+        t = self.torch
+        buf = t.zeros((self.num_envs, 8), dtype=t.float32, device=self.device)
+        self.engine.get("meta", buf.data_ptr(), self._stream())
+        t.cuda.synchronize(self.device)
+        m = buf.view(t.int32).to(t.int64).sum(dim=0).cpu().numpy()
+        return {"step_count": int(m[1]), "rows": int(m[3]), "nan_resets": int(m[4]), "newton_iters": int(m[5]),
+                "ls_evals": int(m[6]), "factorisations": int(m[7])}
+
     def render(self):
         pass  # headless
 

@@ -88,7 +88,8 @@ struct DevObs {
 struct Layout {
   // state record
   int s_qpos, s_qvel, s_warm, s_delay, s_lastact, s_cache, s_stack, s_meta, s_stride;
-  // meta words (int bits): [0] sim_step [1] step_count [2] has_prev [3] episode [4] nan_resets
+  // meta words (int bits): [0] sim_step [1] step_count [2] has_prev [3] sum nefc [4] nan_resets [5] Newton iterations
+  // [6] line-search evaluations [7] Hessian factorisations (cumulative since creation; [3] per substep)
   // parameter record
   int p_mass, p_binvw, p_dinvw, p_floss, p_gmu, p_kp, p_kd, p_mean, p_stride;
 };

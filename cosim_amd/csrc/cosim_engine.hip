@@ -436,6 +436,7 @@ static int locate(cosim_engine* e, const std::string& n, int* off, int* width) {
   if (n == "qpos") { *off = e->lay.s_qpos; *width = e->model.nq; }
   else if (n == "qvel") { *off = e->lay.s_qvel; *width = e->model.nv; }
   else if (n == "qacc_warmstart") { *off = e->lay.s_warm; *width = e->model.nv; }
+  else if (n == "meta") { *off = e->lay.s_meta; *width = 8; }
   else return fail(COSIM_EINVAL, "unknown state field " + n);
   return COSIM_OK;
 }

@@ -185,43 +185,37 @@ struct EnvLds {
   float com[4];
 };
 
-// ------------------------------------------------------------------------------------------------ Cholesky in registers
-// Lane i < NV holds row i of a symmetric positive definite matrix in a[0..NV).  On exit a[k], k <= i, is L[i][k] and
-// a[k], k > i, is L[k][i] (row i of L^T); dinv is 1 / L[i][i].  Right-looking, column j broadcast with v_readlane.
+// ------------------------------------------------------------------------------------------------ Cholesky
+// Lane i < NV holds row i of a symmetric positive definite matrix in a[0..NV).  Right-looking factorisation with the
+// pivot column broadcast by v_readlane; only the lower triangle is meaningful on exit (a[k], k <= i, is L[i][k]; slots
+// k > i hold garbage, which is why no lane masking is needed: 2 VALU per (j,k) pair).  dinv is 1 / L[i][i].
 template <int NV>
-__device__ __forceinline__ void chol_regs(float (&a)[NV], float& dinv, int lane) {
+__device__ __forceinline__ void chol_lower(float (&a)[NV], float& dinv, int lane) {
 #pragma unroll
   for (int j = 0; j < NV; j++) {
-    float ajj = rl(a[j], j);
-    float inv = rsqrtf(fmaxf(ajj, 1e-30f));
-    if (lane == j) dinv = inv;
-    if (lane >= j) a[j] *= inv;  // column j of L (lane j: L[j][j])
+    const float ajj = rl(a[j], j);
+    const float inv = rsqrtf(fmaxf(ajj, 1e-30f));
+    dinv = (lane == j) ? inv : dinv;
+    a[j] *= inv;  // column j of L in lanes >= j
 #pragma unroll
-    for (int k = j + 1; k < NV; k++) {
-      float t = a[k] * inv;
-      a[k] = (lane == j) ? t : a[k];  // row j of L^T
-    }
-#pragma unroll
-    for (int k = j + 1; k < NV; k++) {
-      float lkj = rl(a[k], j);
-      float upd = a[k] - a[j] * lkj;
-      a[k] = (lane > j) ? upd : a[k];
-    }
+    for (int k = j + 1; k < NV; k++) a[k] -= a[j] * rl(a[j], k);  // rl(a[j], k) = L[k][j]
   }
 }
-// solve (L L^T) x = b; lane i holds b_i and returns x_i
-template <int NV>
-__device__ __forceinline__ float chol_solve_regs(const float (&a)[NV], float dinv, float b, int lane) {
+// solve (L L^T) x = b with L stored row-major in LDS (Lm[i][k], k <= i valid); lane i holds b_i and returns x_i.
+// Forward substitution reads row i, backward substitution reads column i (consecutive lanes -> consecutive banks).
+template <int NV, int LD>
+__device__ __forceinline__ float chol_solve_lds(const float (*Lm)[LD], float dinv, float b, int lane) {
+  const int li = lane < NV ? lane : 0;
 #pragma unroll
   for (int j = 0; j < NV; j++) {
-    float yj = rl(b, j) * rl(dinv, j);
-    float upd = b - a[j] * yj;
+    const float yj = rl(b, j) * rl(dinv, j);
+    const float upd = b - Lm[li][j] * yj;
     b = (lane == j) ? yj : ((lane > j) ? upd : b);
   }
 #pragma unroll
   for (int j = NV - 1; j >= 0; j--) {
-    float xj = rl(b, j) * rl(dinv, j);
-    float upd = b - a[j] * xj;
+    const float xj = rl(b, j) * rl(dinv, j);
+    const float upd = b - Lm[j][li] * xj;
     b = (lane == j) ? xj : ((lane < j) ? upd : b);
   }
   return b;
@@ -305,6 +299,7 @@ __global__ __launch_bounds__(64, 4) void env_kernel(KArgs A) {
   float prev_action = 0.f;  // lane u: self.prev_action (raw action of the previous step)
   float tq_lane = 0.f;
   int terminated = 0, truncated = 0, bad = 0;
+  int st_newton = 0, st_ls = 0, st_build = 0, st_rows = 0;  // solver statistics of this control step
 
   if (A.mode != MODE_RESET) {
     // ---- state -> LDS
@@ -931,6 +926,7 @@ __global__ __launch_bounds__(64, 4) void env_kernel(KArgs A) {
       int niter = 0;
       const int maxiter = min(dm.iterations, A.max_newton);
 
+      float dact_cur = 0.f, dact_fac = -1.f;  // this row's active D now / when H was last factorised
       auto update_constraint = [&]() {
         // mj_constraintUpdate: force, active set, cost
         float f = 0.f, c = 0.f, dact = 0.f;
@@ -943,6 +939,7 @@ __global__ __launch_bounds__(64, 4) void env_kernel(KArgs A) {
         } else if (rtype == RT_LIMIT || rtype == RT_CONTACT) {
           if (Jaref < 0.f) { f = -rD * Jaref; c = 0.5f * rD * Jaref * Jaref; dact = rD; }
         }
+        dact_cur = dact;
         S.w.r.rowf[ln] = f;
         S.w.r.rowD[ln] = dact;
         if (ln < NV) { S.dofD[ln] = 0.f; S.qcon[ln] = 0.f; }
@@ -964,38 +961,49 @@ __global__ __launch_bounds__(64, 4) void env_kernel(KArgs A) {
       };
 
       auto update_search = [&]() {
-        // Hessian H = M + J^T diag(D_active) J, entry-parallel over the lower triangle, mirrored into a full square
-        {
-          int ea[EPL], eb[EPL];
-          float hacc[EPL];
+        // H = M + J^T diag(D_active) J changes only when the active set does (mj_solNewton rebuilds on state changes):
+        // otherwise the factor left in LDS by the previous iteration is reused.
+        if (__ballot(dact_cur != dact_fac) != 0ull) {
+          dact_fac = dact_cur;
+          st_build++;
+          {  // entry-parallel over the lower triangle, mirrored into a full square
+            int ea[EPL], eb[EPL];
+            float hacc[EPL];
 #pragma unroll
-          for (int t = 0; t < EPL; t++) {
-            const int e = ln + 64 * t;
-            ea[t] = e < TRI ? dm.tri_row[e] : 0;
-            eb[t] = e < TRI ? dm.tri_col[e] : 0;
-            hacc[t] = S.M[ea[t]][eb[t]];
+            for (int t = 0; t < EPL; t++) {
+              const int e = ln + 64 * t;
+              ea[t] = e < TRI ? dm.tri_row[e] : 0;
+              eb[t] = e < TRI ? dm.tri_col[e] : 0;
+              hacc[t] = S.M[ea[t]][eb[t]];
+            }
+            for (int r = 0; r < ngen; r++) {
+              const float dr = rfl(S.w.r.rowD[r]);
+              if (dr == 0.f) continue;
+              const float* Jr = S.J[r];
+#pragma unroll
+              for (int t = 0; t < EPL; t++) hacc[t] += dr * Jr[ea[t]] * Jr[eb[t]];
+            }
+#pragma unroll
+            for (int t = 0; t < EPL; t++)
+              if (ln + 64 * t < TRI) { S.u.H[ea[t]][eb[t]] = hacc[t]; S.u.H[eb[t]][ea[t]] = hacc[t]; }
           }
-          for (int r = 0; r < ngen; r++) {
-            const float dr = rfl(S.w.r.rowD[r]);
-            if (dr == 0.f) continue;
-            const float* Jr = S.J[r];
+          WSYNC();
+          float a_row[NV];
+          {
+            const float* Hr = S.u.H[ln < NV ? ln : 0];
+            const float dd = ln < NV ? S.dofD[ln] : 0.f;  // unit rows (frictionloss, limits) only touch the diagonal
 #pragma unroll
-            for (int t = 0; t < EPL; t++) hacc[t] += dr * Jr[ea[t]] * Jr[eb[t]];
+            for (int k = 0; k < NV; k++) a_row[k] = (ln < NV ? Hr[k] : 0.f) + ((ln == k) ? dd : 0.f);
           }
+          chol_lower<NV>(a_row, dinv, ln);
+          WSYNC();
+          if (ln < NV) {
 #pragma unroll
-          for (int t = 0; t < EPL; t++)
-            if (ln + 64 * t < TRI) { S.u.H[ea[t]][eb[t]] = hacc[t]; S.u.H[eb[t]][ea[t]] = hacc[t]; }
+            for (int k = 0; k < NV; k++) S.u.H[ln][k] = a_row[k];
+          }
+          WSYNC();
         }
-        WSYNC();
-        float a_row[NV];
-        {
-          const float* Hr = S.u.H[ln < NV ? ln : 0];
-          const float dd = ln < NV ? S.dofD[ln] : 0.f;  // unit rows (frictionloss, limits) only touch the diagonal
-#pragma unroll
-          for (int k = 0; k < NV; k++) a_row[k] = (ln < NV ? Hr[k] : 0.f) + ((ln == k) ? dd : 0.f);
-        }
-        chol_regs<NV>(a_row, dinv, ln);
-        const float mg = chol_solve_regs<NV>(a_row, dinv, grad_l, ln);
+        const float mg = chol_solve_lds<NV, L::LD>(S.u.H, dinv, grad_l, ln);
         if (ln < NV) S.sr[ln] = -mg;
         WSYNC();
       };
@@ -1048,6 +1056,7 @@ __global__ __launch_bounds__(64, 4) void env_kernel(KArgs A) {
           return p;
         };
         float alpha = 0.f;
+        int lsit_total = 0;
         {
           int lsit = 0;
           const int maxls = min(dm.ls_iterations, 24);
@@ -1103,8 +1112,10 @@ __global__ __launch_bounds__(64, 4) void env_kernel(KArgs A) {
               }
             }
           }
+          lsit_total = lsit;
         }
         alpha = rfl(alpha);
+        st_ls += lsit_total;
         if (alpha == 0.f) break;
         // ---- move
         qacc_l += alpha * sr_l;
@@ -1118,6 +1129,8 @@ __global__ __launch_bounds__(64, 4) void env_kernel(KArgs A) {
         const float improvement = scale * (oldcost - cost);
         if (improvement < A.tol32) break;
       }
+      st_newton += niter;
+      st_rows += nefc;
       if (A.mode == MODE_DEBUG && A.dbg != nullptr) {
         float* D = A.dbg;
         if (ln == 0) { D[8] = (float)niter; D[9] = cost; D[10] = gradnorm; }
@@ -1136,9 +1149,15 @@ __global__ __launch_bounds__(64, 4) void env_kernel(KArgs A) {
 #pragma unroll
           for (int k = 0; k < NV; k++) a_row[k] = (ln < NV ? Mr[k] : 0.f) + ((ln == k) ? hd : 0.f);
         }
-        chol_regs<NV>(a_row, dinv, ln);
+        chol_lower<NV>(a_row, dinv, ln);
+        WSYNC();
+        if (ln < NV) {
+#pragma unroll
+          for (int k = 0; k < NV; k++) S.u.H[ln][k] = a_row[k];
+        }
+        WSYNC();
         const float rhs = ln < NV ? qsm_l + S.qcon[ln] : 0.f;
-        const float qa = chol_solve_regs<NV>(a_row, dinv, rhs, ln);
+        const float qa = chol_solve_lds<NV, L::LD>(S.u.H, dinv, rhs, ln);
         WSYNC();
         if (A.mode != MODE_DEBUG) {
           if (ln < NV) S.qvel[ln] = qv + h * qa;
@@ -1280,7 +1299,10 @@ __global__ __launch_bounds__(64, 4) void env_kernel(KArgs A) {
   if (lane < nq) rec[lay.s_qpos + lane] = S.qpos[lane];
   if (lane < NV) { rec[lay.s_qvel + lane] = S.qvel[lane]; rec[lay.s_warm + lane] = S.qacc[lane]; }
   if (lane < nu) rec[lay.s_lastact + lane] = do_reset ? 0.f : raw_action;
-  if (lane == 0) { meta[0] = sim_step; meta[1] = (int)(step_count + 1u); meta[2] = has_prev; meta[4] = nan_resets; }
+  if (lane == 0) {
+    meta[0] = sim_step; meta[1] = (int)(step_count + 1u); meta[2] = has_prev; meta[4] = nan_resets;
+    meta[5] += st_newton; meta[6] += st_ls; meta[7] += st_build; meta[3] += st_rows;
+  }
 }
 
 }  // namespace cosim
