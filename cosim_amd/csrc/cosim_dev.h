@@ -58,6 +58,7 @@ struct DevModel {
   int imu_body, term_mode, nterm_body, ntri;
   int nobs_pos, nobs_vel, ninfo_state, init_noise_nq;
   unsigned imu_dofmask;
+  unsigned term_bodymask;  // bodies whose cfrc_ext ends the episode (term_mode 1)
   float timestep, tolerance, ls_tolerance, impratio;
   float gravity[3];
   float ground_pos[3];

@@ -51,9 +51,9 @@ struct cosim_engine {
   int lds_bytes = 0;
 };
 
-template <int NV, int NB>
+template <int NV, int NB, int RPL>
 static void launch_t(cosim_engine* e, const KArgs& a, int grid, hipStream_t s) {
-  hipLaunchKernelGGL((env_kernel<NV, NB>), dim3(grid), dim3(64), 0, s, a);
+  hipLaunchKernelGGL((env_kernel<NV, NB, RPL>), dim3(grid), dim3(64), 0, s, a);
 }
 
 static int round_up(int x, int m) { return (x + m - 1) / m * m; }
@@ -72,7 +72,6 @@ static int build_dev_model(cosim_engine* e) {
   d.gyro_cutoff = (float)m.gyro_cutoff; d.vel_cutoff = (float)m.velocimeter_cutoff; d.heightmap_miss = (float)m.heightmap_miss;
   if (m.solver != CS_SOLVER_NEWTON) return fail(COSIM_EINVAL, "only solver=\"Newton\" (the reference models' setting) is implemented");
   if (m.ground_type != CS_GEOM_PLANE) return fail(COSIM_EINVAL, "heightfield terrain is not implemented in the HIP engine yet (flat only)");
-  if (m.npair != 0) return fail(COSIM_EINVAL, "robot self-collision pairs are not implemented in the HIP engine yet");
   if (m.nbody > 32 || m.nv > 32 || m.ngeom > 32 || m.nq > 64) return fail(COSIM_EINVAL, "model exceeds the per-lane record capacity");
   if (m.neq > MAXEQ) return fail(COSIM_EINVAL, "too many equalities");
   int maxdepth = 0;
@@ -174,6 +173,7 @@ static int build_dev_model(cosim_engine* e) {
   for (int i = 0; i < CS_MAXINFOSTATE; i++) { d.rec[i].i_kind = m.info_kind[i]; d.rec[i].i_adr = m.info_adr[i]; d.rec[i].i_gear = (float)m.info_gear[i]; }
   for (int i = 0; i < CS_MAXQ; i++) { d.rec[i].n_qadr = m.init_noise_qadr[i]; d.rec[i].init_qpos = (float)m.init_qpos[i]; }
   for (int i = 0; i < CS_MAXBODY; i++) d.rec[i].t_body = m.term_body[i];
+  for (int i = 0; i < m.nterm_body; i++) d.term_bodymask |= 1u << m.term_body[i];
   d.ntri = m.nv * (m.nv + 1) / 2;
   for (int r = 0, e2 = 0; r < m.nv; r++)
     for (int c = 0; c <= r; c++, e2++) { d.tri_row[e2] = (unsigned char)r; d.tri_col[e2] = (unsigned char)c; }
@@ -287,10 +287,11 @@ int cosim_create(const cosim_model_t* model, const float* hull_vert, const int* 
   if (rc != COSIM_OK) { delete e; return rc; }
   build_layout(e);
   const int nv = model->nv, nb = model->nbody;
-  if (nv == 18 && nb <= 14) { e->launch = launch_t<18, 14>; e->lds_bytes = (int)sizeof(EnvLds<18, 14>); }
-  else if (nv == 14 && nb <= 10) { e->launch = launch_t<14, 10>; e->lds_bytes = (int)sizeof(EnvLds<14, 10>); }
-  else if (nv == 6 && nb <= 2) { e->launch = launch_t<6, 2>; e->lds_bytes = (int)sizeof(EnvLds<6, 2>); }
-  else if (nv == 8 && nb <= 4) { e->launch = launch_t<8, 4>; e->lds_bytes = (int)sizeof(EnvLds<8, 4>); }
+  // kernel instantiations: (nv, nbody) of the four cosim robots; RPL = constraint rows per lane
+  if (nv == 18 && nb <= 14) { e->launch = launch_t<18, 14, 1>; e->lds_bytes = (int)sizeof(EnvLds<18, 14, 1>); }        // flamingo_light_v1
+  else if (nv == 14 && nb <= 10) { e->launch = launch_t<14, 10, 2>; e->lds_bytes = (int)sizeof(EnvLds<14, 10, 2>); }   // flamingo_p_v3
+  else if (nv == 22 && nb <= 18) { e->launch = launch_t<22, 18, 2>; e->lds_bytes = (int)sizeof(EnvLds<22, 18, 2>); }   // w4_p_v2
+  else if (nv == 29 && nb <= 26) { e->launch = launch_t<29, 26, 2>; e->lds_bytes = (int)sizeof(EnvLds<29, 26, 2>); }   // humanoid_p_v0
   else { delete e; return fail(COSIM_EINVAL, "cosim_create: no kernel instantiation for this (nv, nbody); add one in cosim_engine.hip"); }
   HIP_TRY(hipMalloc(&e->d_model, sizeof(DevModel)));
   HIP_TRY(hipMalloc(&e->d_obs, sizeof(DevObs)));

@@ -157,12 +157,13 @@ __device__ __forceinline__ unsigned philox_first(unsigned k0, unsigned k1, unsig
 __device__ __forceinline__ float u01(unsigned x) { return (float)(x >> 8) * (1.0f / 16777216.0f) + (0.5f / 16777216.0f); }  // (0,1)
 
 // ------------------------------------------------------------------------------------------------ LDS per env
-template <int NV, int NB>
+template <int NV, int NB, int RPL>
 struct EnvLds {
   static constexpr int LD = NV | 1;   // odd leading dimension: conflict-free column access
-  static constexpr int MC = 12;       // contact slots (4 pyramid rows each)
+  static constexpr int ROWS = 64 * RPL;            // constraint rows per env: RPL rows per lane
+  static constexpr int MC = RPL == 1 ? 12 : 16;    // contact slots (4 pyramid rows each)
   static constexpr int NGEN = 3 * MAXEQ / 2 + 4 * MC;  // dense rows: 2 connect equalities (6 rows) + contacts
-  static constexpr int NLIM = 8;
+  static constexpr int NLIM = 8 * RPL;
   float qpos[CS_MAXQ], qvel[NV], qacc[NV], qact[NV], qsm[NV], qcon[NV], sr[NV], dofD[NV];
   float xpos[NB][3], xquat[NB][4], xanc[NB][3], xax[NB][3];
   float cdof[NV][6];
@@ -173,7 +174,7 @@ struct EnvLds {
   } u;
   union {
     float cin[NB][10];         // dead after the bias forces
-    struct { float rowf[MAXROW], rowD[MAXROW]; } r;
+    struct { float rowf[ROWS], rowD[ROWS]; } r;
   } w;
   float J[NGEN][LD];
   float cpos[MC][3], cnrm[MC][3], cdist[MC];
@@ -238,9 +239,10 @@ __device__ __forceinline__ float impedance(const float* solimp, float pos, float
 }
 
 // ------------------------------------------------------------------------------------------------ the kernel
-template <int NV, int NB>
-__global__ __launch_bounds__(64, 4) void env_kernel(KArgs A) {
-  using L = EnvLds<NV, NB>;
+template <int NV, int NB, int RPL>
+__global__ __launch_bounds__(64, RPL == 1 ? 4 : 2) void env_kernel(KArgs A) {
+  using L = EnvLds<NV, NB, RPL>;
+  constexpr int MAXROWS = L::ROWS;
   constexpr int TRI = NV * (NV + 1) / 2;
   constexpr int MC = L::MC;
   constexpr int NGENMAX = L::NGEN;
@@ -769,7 +771,7 @@ __global__ __launch_bounds__(64, 4) void env_kernel(KArgs A) {
         if (hi_v && rhi < L::NLIM) { S.lim_body[rhi] = ln; S.lim_sign[rhi] = -1.f; S.lim_dist[rhi] = dhi; }
       }
       {
-        int room = (MAXROW - ne - nf - nl) / 4;
+        int room = (MAXROWS - ne - nf - nl) / 4;
         if (room < 0) room = 0;
         if (ncon > room) ncon = room;
         if (ncon > MC) ncon = MC;
@@ -779,19 +781,22 @@ __global__ __launch_bounds__(64, 4) void env_kernel(KArgs A) {
       const int nefc = ngen + nf + nl;      // then unit rows: frictionloss, limits
       WSYNC();
 
-      int rtype = RT_NONE, rdof = 0;
-      float rsign = 1.f, rfloss = 0.f;
-      float rD = 0.f, rR = 1.f, raref = 0.f, rpos_dbg = 0.f;
-      {
+      // per-lane row state: row (ln + 64 rr), rr < RPL
+      int rtype[RPL], rdof[RPL];
+      float rsign[RPL], rfloss[RPL], rD[RPL], rR[RPL], raref[RPL], rpos_dbg = 0.f;
+#pragma unroll
+      for (int rr = 0; rr < RPL; rr++) {
+        const int row = ln + 64 * rr;
+        rtype[rr] = RT_NONE; rdof[rr] = 0; rsign[rr] = 1.f; rfloss[rr] = 0.f; rD[rr] = 0.f; rR[rr] = 1.f; raref[rr] = 0.f;
         float rpos = 0.f, rmargin = 0.f, rdiagA = 0.f, rmu = 0.f;
         float rsolref[2] = {0.02f, 1.f}, rsolimp[5] = {0.9f, 0.95f, 0.001f, 0.5f, 2.f};
-        if (ln < ngen) {
-          float* Jr = S.J[ln];
+        if (row < ngen) {
+          float* Jr = S.J[row];
 #pragma unroll
           for (int d = 0; d < NV; d++) Jr[d] = 0.f;
-          if (ln < ne) {
-            rtype = RT_EQ;
-            const int e = ln / 3, comp = ln - 3 * e;
+          if (row < ne) {
+            rtype[rr] = RT_EQ;
+            const int e = row / 3, comp = row - 3 * e;
             const LaneRec& E = dm.rec[e];
             const int b1 = E.e_body1, b2 = E.e_body2;
             float dir[3] = {comp == 0 ? 1.f : 0.f, comp == 1 ? 1.f : 0.f, comp == 2 ? 1.f : 0.f};
@@ -819,8 +824,8 @@ __global__ __launch_bounds__(64, 4) void env_kernel(KArgs A) {
             for (int k = 0; k < 2; k++) rsolref[k] = E.e_solref[k];
             for (int k = 0; k < 5; k++) rsolimp[k] = E.e_solimp[k];
           } else {
-            rtype = RT_CONTACT;
-            const int c = (ln - ne) >> 2, edge = (ln - ne) & 3;
+            rtype[rr] = RT_CONTACT;
+            const int c = (row - ne) >> 2, edge = (row - ne) & 3;
             const int g = S.cgeom[c];
             const LaneRec& G = dm.rec[g];
             const int b = G.g_body;
@@ -843,32 +848,32 @@ __global__ __launch_bounds__(64, 4) void env_kernel(KArgs A) {
             for (int k = 0; k < 2; k++) rsolref[k] = G.g_solref[k];
             for (int k = 0; k < 5; k++) rsolimp[k] = G.g_solimp[k];
           }
-        } else if (ln < nefc) {
-          if (ln < ngen + nf) {
-            rtype = RT_FRIC;
-            rdof = dm.rec[ln - ngen].d_fric;  // model-level list; a per-env value of zero leaves the row inert
-            const LaneRec& D = dm.rec[rdof];
-            rfloss = S.p_floss[rdof];
-            rdiagA = S.p_dinvw[rdof];
+        } else if (row < nefc) {
+          if (row < ngen + nf) {
+            rtype[rr] = RT_FRIC;
+            rdof[rr] = dm.rec[row - ngen].d_fric;  // model-level list; a per-env value of zero leaves the row inert
+            const LaneRec& D = dm.rec[rdof[rr]];
+            rfloss[rr] = S.p_floss[rdof[rr]];
+            rdiagA = S.p_dinvw[rdof[rr]];
             for (int k = 0; k < 2; k++) rsolref[k] = D.d_solref[k];
             for (int k = 0; k < 5; k++) rsolimp[k] = D.d_solimp[k];
-            if (!(rfloss > 0.f)) rtype = RT_NONE;
+            if (!(rfloss[rr] > 0.f)) rtype[rr] = RT_NONE;
           } else {
-            rtype = RT_LIMIT;
-            const int li = ln - ngen - nf;
+            rtype[rr] = RT_LIMIT;
+            const int li = row - ngen - nf;
             const int b = S.lim_body[li];
             const LaneRec& B = dm.rec[b];
-            rdof = B.b_dadr;
-            rsign = S.lim_sign[li];
+            rdof[rr] = B.b_dadr;
+            rsign[rr] = S.lim_sign[li];
             rpos = S.lim_dist[li];
             rmargin = B.j_margin;
-            rdiagA = S.p_dinvw[rdof];
+            rdiagA = S.p_dinvw[rdof[rr]];
             for (int k = 0; k < 2; k++) rsolref[k] = B.j_solref[k];
             for (int k = 0; k < 5; k++) rsolimp[k] = B.j_solimp[k];
           }
         }
         // KBIP, R, D, aref
-        if (rtype != RT_NONE) {
+        if (rtype[rr] != RT_NONE) {
           float imp = impedance(rsolimp, rpos, rmargin);
           float dmax = fminf(MAXIMP, fmaxf(MINIMP, rsolimp[1]));
           float K, B;
@@ -877,27 +882,25 @@ __global__ __launch_bounds__(64, 4) void env_kernel(KArgs A) {
             K = 1.f / fmaxf(MINVAL, dmax * dmax * tc * tc * dr * dr);
             B = 2.f / fmaxf(MINVAL, dmax * tc);
           } else { K = -rsolref[0] / fmaxf(MINVAL, dmax * dmax); B = -rsolref[1] / fmaxf(MINVAL, dmax); }
-          if (rtype == RT_FRIC) K = 0.f;
-          rR = fmaxf(MINVAL, (1.f - imp) * rdiagA / imp);
-          if (rtype == RT_CONTACT) { float mu = rmu * rsqrtf(fmaxf(MINVAL, dm.impratio)); rR = 2.f * mu * mu * rR; }
-          rD = 1.f / rR;
+          if (rtype[rr] == RT_FRIC) K = 0.f;
+          rR[rr] = fmaxf(MINVAL, (1.f - imp) * rdiagA / imp);
+          if (rtype[rr] == RT_CONTACT) { float mu = rmu * rsqrtf(fmaxf(MINVAL, dm.impratio)); rR[rr] = 2.f * mu * mu * rR[rr]; }
+          rD[rr] = 1.f / rR[rr];
           float vel;
-          if (rtype == RT_EQ || rtype == RT_CONTACT) {
+          if (rtype[rr] == RT_EQ || rtype[rr] == RT_CONTACT) {
             vel = 0.f;
-            const float* Jr = S.J[ln];
+            const float* Jr = S.J[row];
 #pragma unroll
             for (int d = 0; d < NV; d++) vel += Jr[d] * S.qvel[d];
-          } else vel = rsign * S.qvel[rdof];
-          raref = -B * vel - K * imp * (rpos - rmargin);
+          } else vel = rsign[rr] * S.qvel[rdof[rr]];
+          raref[rr] = -B * vel - K * imp * (rpos - rmargin);
         }
-        rpos_dbg = rpos;
+        if (rr == 0) rpos_dbg = rpos;
       }
-      const bool dense_row = rtype == RT_EQ || rtype == RT_CONTACT;
-      const bool unit_row = rtype == RT_FRIC || rtype == RT_LIMIT;
       WSYNC();
 
       // =========================================================== Newton solver (mj_solNewton), warm-started from qacc
-      float Jaref = 0.f, Jv = 0.f, Ma = 0.f;
+      float Jaref[RPL], Jv[RPL], Ma = 0.f;
       float dinv = 1.f;
       auto mulM = [&](const float* v) -> float {  // (M v)[lane]
         float s = 0.f;
@@ -908,16 +911,17 @@ __global__ __launch_bounds__(64, 4) void env_kernel(KArgs A) {
         }
         return s;
       };
-      auto rowdot = [&](const float* v) -> float {  // J[row] . v for this lane's row
+      auto rowdot = [&](const float* v, int rr) -> float {  // J[row] . v for row (ln + 64 rr)
         float s = 0.f;
-        if (dense_row) {
-          const float* Jr = S.J[ln];
+        if (rtype[rr] == RT_EQ || rtype[rr] == RT_CONTACT) {
+          const float* Jr = S.J[ln + 64 * rr];
 #pragma unroll
           for (int d = 0; d < NV; d++) s += Jr[d] * v[d];
-        } else if (unit_row) s = rsign * v[rdof];
+        } else if (rtype[rr] == RT_FRIC || rtype[rr] == RT_LIMIT) s = rsign[rr] * v[rdof[rr]];
         return s;
       };
-      Jaref = rtype == RT_NONE ? 0.f : rowdot(S.qacc) - raref;
+#pragma unroll
+      for (int rr = 0; rr < RPL; rr++) { Jaref[rr] = rtype[rr] == RT_NONE ? 0.f : rowdot(S.qacc, rr) - raref[rr]; Jv[rr] = 0.f; }
       Ma = mulM(S.qacc);
       float qacc_l = ln < NV ? S.qacc[ln] : 0.f;
       const float qsm_l = ln < NV ? S.qsm[ln] : 0.f;
@@ -926,28 +930,38 @@ __global__ __launch_bounds__(64, 4) void env_kernel(KArgs A) {
       int niter = 0;
       const int maxiter = min(dm.iterations, A.max_newton);
 
-      float dact_cur = 0.f, dact_fac = -1.f;  // this row's active D now / when H was last factorised
+      float dact_cur[RPL], dact_fac[RPL];  // this row's active D now / when H was last factorised
+#pragma unroll
+      for (int rr = 0; rr < RPL; rr++) { dact_cur[rr] = 0.f; dact_fac[rr] = -1.f; }
       auto update_constraint = [&]() {
         // mj_constraintUpdate: force, active set, cost
-        float f = 0.f, c = 0.f, dact = 0.f;
-        if (rtype == RT_EQ) { f = -rD * Jaref; c = 0.5f * rD * Jaref * Jaref; dact = rD; }
-        else if (rtype == RT_FRIC) {
-          float Rf = rR * rfloss;
-          if (Jaref <= -Rf) { f = rfloss; c = -0.5f * Rf * rfloss - rfloss * Jaref; }
-          else if (Jaref >= Rf) { f = -rfloss; c = -0.5f * Rf * rfloss + rfloss * Jaref; }
-          else { f = -rD * Jaref; c = 0.5f * rD * Jaref * Jaref; dact = rD; }
-        } else if (rtype == RT_LIMIT || rtype == RT_CONTACT) {
-          if (Jaref < 0.f) { f = -rD * Jaref; c = 0.5f * rD * Jaref * Jaref; dact = rD; }
-        }
-        dact_cur = dact;
-        S.w.r.rowf[ln] = f;
-        S.w.r.rowD[ln] = dact;
+        float csum = 0.f;
         if (ln < NV) { S.dofD[ln] = 0.f; S.qcon[ln] = 0.f; }
-        WSYNC();
-        if (unit_row) {
-          atomicAdd(&S.dofD[rdof], dact);
-          atomicAdd(&S.qcon[rdof], rsign * f);
+#pragma unroll
+        for (int rr = 0; rr < RPL; rr++) {
+          const float x = Jaref[rr];
+          float f = 0.f, c = 0.f, dact = 0.f;
+          if (rtype[rr] == RT_EQ) { f = -rD[rr] * x; c = 0.5f * rD[rr] * x * x; dact = rD[rr]; }
+          else if (rtype[rr] == RT_FRIC) {
+            float Rf = rR[rr] * rfloss[rr];
+            if (x <= -Rf) { f = rfloss[rr]; c = -0.5f * Rf * rfloss[rr] - rfloss[rr] * x; }
+            else if (x >= Rf) { f = -rfloss[rr]; c = -0.5f * Rf * rfloss[rr] + rfloss[rr] * x; }
+            else { f = -rD[rr] * x; c = 0.5f * rD[rr] * x * x; dact = rD[rr]; }
+          } else if (rtype[rr] == RT_LIMIT || rtype[rr] == RT_CONTACT) {
+            if (x < 0.f) { f = -rD[rr] * x; c = 0.5f * rD[rr] * x * x; dact = rD[rr]; }
+          }
+          dact_cur[rr] = dact;
+          csum += c;
+          S.w.r.rowf[ln + 64 * rr] = f;
+          S.w.r.rowD[ln + 64 * rr] = dact;
         }
+        WSYNC();
+#pragma unroll
+        for (int rr = 0; rr < RPL; rr++)
+          if (rtype[rr] == RT_FRIC || rtype[rr] == RT_LIMIT) {
+            atomicAdd(&S.dofD[rdof[rr]], dact_cur[rr]);
+            atomicAdd(&S.qcon[rdof[rr]], rsign[rr] * S.w.r.rowf[ln + 64 * rr]);
+          }
         WSYNC();
         float qc = 0.f;
         if (ln < NV) {
@@ -956,15 +970,19 @@ __global__ __launch_bounds__(64, 4) void env_kernel(KArgs A) {
           S.qcon[ln] = qc;
         }
         gauss = wave_sum(ln < NV ? (0.5f * Ma - qsm_l) * qacc_l : 0.f);
-        cost = wave_sum(c) + gauss;
+        cost = wave_sum(csum) + gauss;
         grad_l = ln < NV ? Ma - qsm_l - qc : 0.f;
       };
 
       auto update_search = [&]() {
         // H = M + J^T diag(D_active) J changes only when the active set does (mj_solNewton rebuilds on state changes):
         // otherwise the factor left in LDS by the previous iteration is reused.
-        if (__ballot(dact_cur != dact_fac) != 0ull) {
-          dact_fac = dact_cur;
+        bool changed = false;
+#pragma unroll
+        for (int rr = 0; rr < RPL; rr++) changed = changed || (dact_cur[rr] != dact_fac[rr]);
+        if (__ballot(changed) != 0ull) {
+#pragma unroll
+          for (int rr = 0; rr < RPL; rr++) dact_fac[rr] = dact_cur[rr];
           st_build++;
           {  // entry-parallel over the lower triangle, mirrored into a full square
             int ea[EPL], eb[EPL];
@@ -1017,7 +1035,7 @@ __global__ __launch_bounds__(64, 4) void env_kernel(KArgs A) {
         if (ln < nbody) { for (int k = 0; k < 3; k++) D[64 + ln * 3 + k] = S.xpos[ln][k]; for (int k = 0; k < 4; k++) D[192 + ln * 4 + k] = S.xquat[ln][k]; }
         for (int e = ln; e < TRI; e += 64) D[512 + e] = S.M[dm.tri_row[e]][dm.tri_col[e]];
         if (ln < NV) { D[1100 + ln] = S.qsm[ln]; for (int q = 0; q < 6; q++) D[1200 + ln * 6 + q] = S.cdof[ln][q]; }
-        D[1400 + ln] = (float)rtype; D[1464 + ln] = rD; D[1528 + ln] = raref; D[1592 + ln] = rpos_dbg; D[1656 + ln] = Jaref;
+        D[1400 + ln] = (float)rtype[0]; D[1464 + ln] = rD[0]; D[1528 + ln] = raref[0]; D[1592 + ln] = rpos_dbg; D[1656 + ln] = Jaref[0];
         if (ln < ngen) for (int d = 0; d < NV; d++) D[2048 + ln * NV + d] = S.J[ln][d];
         if (ln < MC) { D[1720 + ln] = ln < ncon ? S.cdist[ln] : 0.f; for (int k = 0; k < 3; k++) D[1740 + ln * 3 + k] = ln < ncon ? S.cpos[ln][k] : 0.f; }
       }
@@ -1028,23 +1046,31 @@ __global__ __launch_bounds__(64, 4) void env_kernel(KArgs A) {
         // ---- exact line search on the piecewise-quadratic cost (PrimalSearch)
         const float sr_l = ln < NV ? S.sr[ln] : 0.f;
         const float Mv = mulM(S.sr);
-        Jv = rowdot(S.sr);
+        float q0[RPL], q1[RPL], q2[RPL];
+#pragma unroll
+        for (int rr = 0; rr < RPL; rr++) {
+          Jv[rr] = rowdot(S.sr, rr);
+          q0[rr] = 0.5f * rD[rr] * Jaref[rr] * Jaref[rr]; q1[rr] = rD[rr] * Jaref[rr] * Jv[rr]; q2[rr] = 0.5f * rD[rr] * Jv[rr] * Jv[rr];
+        }
         const float snorm = sqrtf(wave_sum(sr_l * sr_l));
         if (!(snorm >= 1e-20f)) break;
         const float qG1 = wave_sum(sr_l * (Ma - qsm_l)), qG2 = wave_sum(0.5f * sr_l * Mv);
-        const float q0 = 0.5f * rD * Jaref * Jaref, q1 = rD * Jaref * Jv, q2 = 0.5f * rD * Jv * Jv;
         const float gtol = A.tol32 * dm.ls_tolerance * snorm / scale;
         struct Pnt { float alpha, cost, d0, d1; };
         auto eval = [&](float alpha) -> Pnt {
-          float x = Jaref + alpha * Jv, c0 = 0.f, c1 = 0.f, c2 = 0.f;
-          if (rtype == RT_EQ) { c0 = q0; c1 = q1; c2 = q2; }
-          else if (rtype == RT_FRIC) {
-            float Rf = rR * rfloss;
-            if (x > -Rf && x < Rf) { c0 = q0; c1 = q1; c2 = q2; }
-            else if (x <= -Rf) { c0 = rfloss * (-0.5f * Rf - Jaref); c1 = -rfloss * Jv; }
-            else { c0 = rfloss * (-0.5f * Rf + Jaref); c1 = rfloss * Jv; }
-          } else if (rtype == RT_LIMIT || rtype == RT_CONTACT) {
-            if (x < 0.f) { c0 = q0; c1 = q1; c2 = q2; }
+          float c0 = 0.f, c1 = 0.f, c2 = 0.f;
+#pragma unroll
+          for (int rr = 0; rr < RPL; rr++) {
+            const float x = Jaref[rr] + alpha * Jv[rr];
+            if (rtype[rr] == RT_EQ) { c0 += q0[rr]; c1 += q1[rr]; c2 += q2[rr]; }
+            else if (rtype[rr] == RT_FRIC) {
+              float Rf = rR[rr] * rfloss[rr];
+              if (x > -Rf && x < Rf) { c0 += q0[rr]; c1 += q1[rr]; c2 += q2[rr]; }
+              else if (x <= -Rf) { c0 += rfloss[rr] * (-0.5f * Rf - Jaref[rr]); c1 += -rfloss[rr] * Jv[rr]; }
+              else { c0 += rfloss[rr] * (-0.5f * Rf + Jaref[rr]); c1 += rfloss[rr] * Jv[rr]; }
+            } else if (rtype[rr] == RT_LIMIT || rtype[rr] == RT_CONTACT) {
+              if (x < 0.f) { c0 += q0[rr]; c1 += q1[rr]; c2 += q2[rr]; }
+            }
           }
           float C0 = wave_sum(c0) + gauss, C1 = wave_sum(c1) + qG1, C2 = wave_sum(c2) + qG2;
           Pnt p;
@@ -1120,7 +1146,8 @@ __global__ __launch_bounds__(64, 4) void env_kernel(KArgs A) {
         // ---- move
         qacc_l += alpha * sr_l;
         Ma += alpha * Mv;
-        Jaref += alpha * Jv;
+#pragma unroll
+        for (int rr = 0; rr < RPL; rr++) Jaref[rr] += alpha * Jv[rr];
         if (ln < NV) S.qacc[ln] = qacc_l;
         const float oldcost = cost;
         update_constraint();
@@ -1138,6 +1165,31 @@ __global__ __launch_bounds__(64, 4) void env_kernel(KArgs A) {
         D[1800 + ln] = S.w.r.rowf[ln];
         if (ln < 4) D[16 + ln] = s_quat[ln];
         if (ln < 3) { D[20 + ln] = s_gyro[ln]; D[24 + ln] = s_vel[ln]; }
+      }
+
+      // =========================================================== _is_done of flamingo_p_v3 (flamingo_p_v3.py:225-233)
+      // cfrc_ext of mj_rnePostConstraint for the listed bodies: sum of contact wrenches [torque; force], world aligned,
+      // about the tree's CoM; "any signed component > 1.0" terminates.  Uses the last substep's contacts and forces.
+      if (dm.term_mode == 1 && sub == nsub - 1) {
+        bool hit = false;
+        if (ln > 0 && ln < nbody && ((dm.term_bodymask >> ln) & 1u)) {
+          float wr[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+          for (int c = 0; c < ncon; c++) {
+            const int g = S.cgeom[c];
+            if (dm.rec[g].g_body != ln) continue;
+            const float mu = S.p_gmu[g];
+            const float* f = &S.w.r.rowf[ne + 4 * c];
+            float nrm[3] = {S.cnrm[c][0], S.cnrm[c][1], S.cnrm[c][2]}, t1[3], t2[3];
+            make_frame(nrm, t1, t2);
+            const float fl0 = f[0] + f[1] + f[2] + f[3], fl1 = (f[0] - f[1]) * mu, fl2 = (f[2] - f[3]) * mu;  // mj_contactForce, pyramidal
+            float fw[3], dif[3], tq[3];
+            for (int k = 0; k < 3; k++) { fw[k] = nrm[k] * fl0 + t1[k] * fl1 + t2[k] * fl2; dif[k] = S.cpos[c][k] - com[k]; }
+            cross(tq, dif, fw);
+            for (int k = 0; k < 3; k++) { wr[k] += tq[k]; wr[3 + k] += fw[k]; }
+          }
+          for (int k = 0; k < 6; k++) hit = hit || (wr[k] > 1.0f);
+        }
+        if (__ballot(hit) != 0ull) terminated = 1;
       }
 
       // =========================================================== mj_implicit (implicitfast) + mj_advance

@@ -26,7 +26,7 @@ extern "C" {
 #define CS_MAXEQ 4
 #define CS_MAXU 24
 #define CS_MAXOBSJ 24  /* joints gathered into dof_pos / dof_vel */
-#define CS_MAXPAIR 64  /* robot-robot geom pairs that pass the contype/conaffinity + exclude filter */
+#define CS_MAXPAIR 256 /* robot-robot geom pairs that pass the contype/conaffinity + exclude filter */
 #define CS_MAXINFOSTATE 24
 
 /* mjtJoint / mjtGeom values */

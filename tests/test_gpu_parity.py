@@ -287,3 +287,51 @@ def test_single_env_adapter_keeps_reference_api(parity):
     d = env.get_data()
     assert d.qvel[0] == pytest.approx(0.3, abs=1e-6) and d.qvel[2] == pytest.approx(0.1, abs=1e-6)
     env.close()
+
+
+@pytest.mark.parametrize("env_id,steps", [("flamingo_p_v3", 45), ("w4_p_v2", 100), ("humanoid_p_v0", 80)])
+def test_other_robots_one_control_step_replay_flat(env_id, steps):
+    """The other three robots on flat ground (nv 14 / 22 / 29; two constraint rows per lane, geared legs, box and
+    cylinder and convex-hull feet / wheels, free-joint armature + frictionloss): one-control-step replay of states
+    along an oracle trajectory.  Robot self-collision pairs are compiled but not collided by either side."""
+    import torch
+    from cosim_amd.batched_env import BatchedEnv
+    from cosim_amd.compile import compile_model
+    from cosim_amd.config import PARITY_RANDOM, make_config
+    from cosim_amd.model import get_field
+    from oracle.oracle import Oracle
+    cfg = make_config(env_id, random=PARITY_RANDOM)
+    cm = compile_model(cfg)
+    b = cm.blob
+    o = Oracle(cm)
+    o.reset(np.array(get_field(b, "init_qpos")[:b.nq]))
+    rng = np.random.default_rng(3)
+    R = dict(qpos=[], qvel=[], warm=[], act=[], qpos1=[], qvel1=[], tq=[], nefc=[], term=[])
+    for t in range(steps):
+        a = np.clip(0.15 * rng.normal(size=b.nu), -1, 1)
+        R["qpos"].append(o.qpos.copy()); R["qvel"].append(o.qvel.copy()); R["warm"].append(o.qacc_warmstart.copy()); R["act"].append(a)
+        tq = o.control_step(a)
+        R["qpos1"].append(o.qpos.copy()); R["qvel1"].append(o.qvel.copy()); R["tq"].append(tq); R["nefc"].append(o.nefc)
+        term = False
+        if b.term_mode == 1:
+            ids = list(get_field(b, "term_body")[:b.nterm_body])
+            term = bool((o.cfrc_ext[ids] > 1.0).any())
+        R["term"].append(term)
+    R = {k: np.array(v) for k, v in R.items()}
+    env = BatchedEnv(cfg, num_envs=steps, auto_reset=False, compiled=cm)
+    env.reset()
+    env.set_state(R["qpos"], R["qvel"], R["warm"])
+    _, term, _, info = env.step(torch.tensor(R["act"], dtype=torch.float32, device=env.device))
+    d = env.get_data()
+    qp, qv = d.qpos.cpu().numpy().astype(np.float64), d.qvel.cpu().numpy().astype(np.float64)
+    np.testing.assert_allclose(info["torque"].cpu().numpy(), R["tq"], rtol=1e-4, atol=2e-3)
+    ok = R["nefc"] <= 100                                       # inside the engine's row capacity
+    assert ok.sum() >= steps * 0.8
+    assert np.abs(qp[ok] - R["qpos1"][ok]).max() < 2e-4, np.abs(qp[ok] - R["qpos1"][ok]).max()
+    ev = np.abs(qv[ok] - R["qvel1"][ok]).max(axis=1)
+    assert ev.max() < 2e-2 and np.median(ev) < 2e-3, (ev.max(), np.median(ev))
+    if b.term_mode == 1:
+        got = term.cpu().numpy().astype(bool)
+        # cfrc_ext termination (flamingo_p_v3.py:225-233): agree except within round-off of the 1.0 threshold
+        assert (got[ok] == R["term"][ok]).mean() > 0.9
+    env.close()
