@@ -51,9 +51,14 @@ struct cosim_engine {
   int lds_bytes = 0;
 };
 
-template <int NV, int NB, int RPL>
+template <int NV, int NB, int RPL, bool HF>
 static void launch_t(cosim_engine* e, const KArgs& a, int grid, hipStream_t s) {
-  hipLaunchKernelGGL((env_kernel<NV, NB, RPL>), dim3(grid), dim3(64), 0, s, a);
+  hipLaunchKernelGGL((env_kernel<NV, NB, RPL, HF>), dim3(grid), dim3(64), 0, s, a);
+}
+template <int NV, int NB, int RPL>
+static void select_t(cosim_engine* e, bool hf) {
+  e->launch = hf ? launch_t<NV, NB, RPL, true> : launch_t<NV, NB, RPL, false>;
+  e->lds_bytes = (int)sizeof(EnvLds<NV, NB, RPL>);
 }
 
 static int round_up(int x, int m) { return (x + m - 1) / m * m; }
@@ -71,7 +76,7 @@ static int build_dev_model(cosim_engine* e) {
   for (int k = 0; k < 4; k++) { d.hfield_size[k] = (float)m.hfield_size[k]; d.imu_quat[k] = (float)m.imu_quat[k]; }
   d.gyro_cutoff = (float)m.gyro_cutoff; d.vel_cutoff = (float)m.velocimeter_cutoff; d.heightmap_miss = (float)m.heightmap_miss;
   if (m.solver != CS_SOLVER_NEWTON) return fail(COSIM_EINVAL, "only solver=\"Newton\" (the reference models' setting) is implemented");
-  if (m.ground_type != CS_GEOM_PLANE) return fail(COSIM_EINVAL, "heightfield terrain is not implemented in the HIP engine yet (flat only)");
+  if (m.ground_type != CS_GEOM_PLANE && (m.hfield_nrow < 2 || m.hfield_ncol < 2)) return fail(COSIM_EINVAL, "heightfield ground without elevation data");
   if (m.nbody > 32 || m.nv > 32 || m.ngeom > 32 || m.nq > 64) return fail(COSIM_EINVAL, "model exceeds the per-lane record capacity");
   if (m.neq > MAXEQ) return fail(COSIM_EINVAL, "too many equalities");
   int maxdepth = 0;
@@ -199,7 +204,8 @@ static int build_dev_obs(cosim_engine* e) {
     for (int i = 0; i < n; i++) {
       int f = list[i];
       if (f < 0 || f > 7) return fail(COSIM_EINVAL, "unknown observation field id");
-      if (f == CS_OBS_HEIGHT_MAP && c.field_dim[f] > 0) return fail(COSIM_EINVAL, "height_map observation needs heightfield terrain, which the HIP engine does not implement yet");
+      if (f == CS_OBS_HEIGHT_MAP && (e->model.ground_type != CS_GEOM_HFIELD || c.hm_res_x * c.hm_res_y != c.field_dim[f] || c.field_dim[f] < 1))
+        return fail(COSIM_EINVAL, "height_map observation needs a heightfield terrain (mj_rayHfield on a plane is an error in the reference too) and res_x * res_y elements");
       int dim = c.field_dim[f];
       if (c.field_interval[f] < 1 && f != CS_OBS_COMMAND) return fail(COSIM_EINVAL, "observation interval must be >= 1");
       for (int k = 0; k < dim; k++) {
@@ -288,10 +294,11 @@ int cosim_create(const cosim_model_t* model, const float* hull_vert, const int* 
   build_layout(e);
   const int nv = model->nv, nb = model->nbody;
   // kernel instantiations: (nv, nbody) of the four cosim robots; RPL = constraint rows per lane
-  if (nv == 18 && nb <= 14) { e->launch = launch_t<18, 14, 1>; e->lds_bytes = (int)sizeof(EnvLds<18, 14, 1>); }        // flamingo_light_v1
-  else if (nv == 14 && nb <= 10) { e->launch = launch_t<14, 10, 2>; e->lds_bytes = (int)sizeof(EnvLds<14, 10, 2>); }   // flamingo_p_v3
-  else if (nv == 22 && nb <= 18) { e->launch = launch_t<22, 18, 2>; e->lds_bytes = (int)sizeof(EnvLds<22, 18, 2>); }   // w4_p_v2
-  else if (nv == 29 && nb <= 26) { e->launch = launch_t<29, 26, 2>; e->lds_bytes = (int)sizeof(EnvLds<29, 26, 2>); }   // humanoid_p_v0
+  const bool hf = model->ground_type == CS_GEOM_HFIELD;
+  if (nv == 18 && nb <= 14) select_t<18, 14, 1>(e, hf);        // flamingo_light_v1
+  else if (nv == 14 && nb <= 10) select_t<14, 10, 2>(e, hf);   // flamingo_p_v3
+  else if (nv == 22 && nb <= 18) select_t<22, 18, 2>(e, hf);   // w4_p_v2
+  else if (nv == 29 && nb <= 26) select_t<29, 26, 2>(e, hf);   // humanoid_p_v0
   else { delete e; return fail(COSIM_EINVAL, "cosim_create: no kernel instantiation for this (nv, nbody); add one in cosim_engine.hip"); }
   HIP_TRY(hipMalloc(&e->d_model, sizeof(DevModel)));
   HIP_TRY(hipMalloc(&e->d_obs, sizeof(DevObs)));
@@ -311,7 +318,12 @@ int cosim_create(const cosim_model_t* model, const float* hull_vert, const int* 
     HIP_TRY(hipMemcpy(e->d_hull_adr, hull_adr, (size_t)(model->nhullvert + 1) * sizeof(int), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(e->d_hull_nbr, hull_nbr, (size_t)model->nhulledge * sizeof(int), hipMemcpyHostToDevice));
   }
-  (void)hfield;
+  if (model->ground_type == CS_GEOM_HFIELD) {
+    if (!hfield) return fail(COSIM_EINVAL, "cosim_create: heightfield ground but no elevation data was passed");
+    size_t nh = (size_t)model->hfield_nrow * model->hfield_ncol;
+    HIP_TRY(hipMalloc(&e->d_hfield, nh * sizeof(float)));
+    HIP_TRY(hipMemcpy(e->d_hfield, hfield, nh * sizeof(float), hipMemcpyHostToDevice));
+  }
   default_params(e);
   *out = e;
   return COSIM_OK;
@@ -321,7 +333,7 @@ int cosim_destroy(cosim_engine_t* e) {
   if (!e) return COSIM_OK;
   hipSetDevice(e->device);
   hipFree(e->d_model); hipFree(e->d_obs); hipFree(e->d_state); hipFree(e->d_params); hipFree(e->d_dbg);
-  hipFree(e->d_hull_vert); hipFree(e->d_hull_adr); hipFree(e->d_hull_nbr);
+  hipFree(e->d_hull_vert); hipFree(e->d_hull_adr); hipFree(e->d_hull_nbr); hipFree(e->d_hfield);
   for (hipEvent_t x : e->ev) hipEventDestroy(x);
   delete e;
   return COSIM_OK;

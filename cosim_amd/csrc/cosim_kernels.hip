@@ -222,6 +222,134 @@ __device__ __forceinline__ float chol_solve_lds(const float (*Lm)[LD], float din
   return b;
 }
 
+
+// ------------------------------------------------------------------------------------------------ geometry helpers
+// Contacts of one primitive geom (sphere / cylinder / box) against the plane through P0 with unit normal n:
+// mjc_PlaneSphere / mjc_PlaneCylinder / mjc_PlaneBox (engine_collision_primitive.c).  Returns the contact count (<= 4).
+__device__ __forceinline__ int prim_plane(const LaneRec& R, const float* xq, const float* xp, const float* P0, const float* n,
+                                          float margin, float (*cp)[3], float* cdst) {
+  int cnt = 0;
+  float v[3], pos[3], gq[4], mat[9];
+  qrot(v, xq, R.g_pos);
+  for (int k = 0; k < 3; k++) pos[k] = xp[k] + v[k];
+  const float dist0 = n[0] * (pos[0] - P0[0]) + n[1] * (pos[1] - P0[1]) + n[2] * (pos[2] - P0[2]);
+  const int gt = R.g_type;
+  if (gt == CS_GEOM_SPHERE) {
+    const float r = R.g_size[0];
+    if (dist0 <= margin + r) {
+      const float dist = dist0 - r;
+      cdst[0] = dist;
+      for (int k = 0; k < 3; k++) cp[0][k] = pos[k] - n[k] * (r + 0.5f * dist);
+      cnt = 1;
+    }
+  } else if (gt == CS_GEOM_CYLINDER) {
+    qmul(gq, xq, R.g_quat);
+    q2m(mat, gq);
+    const float radius = R.g_size[0], half = R.g_size[1];
+    float axis[3] = {mat[2], mat[5], mat[8]};
+    float prjaxis = dot3(n, axis);
+    if (prjaxis > 0.f) { axis[0] = -axis[0]; axis[1] = -axis[1]; axis[2] = -axis[2]; prjaxis = -prjaxis; }
+    float vec[3] = {axis[0] * prjaxis - n[0], axis[1] * prjaxis - n[1], axis[2] * prjaxis - n[2]};
+    const float len = sqrtf(dot3(vec, vec));
+    if (len < 1e-12f) { vec[0] = mat[0] * radius; vec[1] = mat[3] * radius; vec[2] = mat[6] * radius; }
+    else { const float s = radius / len; vec[0] *= s; vec[1] *= s; vec[2] *= s; }
+    const float prjvec = dot3(vec, n);
+    axis[0] *= half; axis[1] *= half; axis[2] *= half;
+    prjaxis *= half;
+    float dist = dist0 + prjaxis + prjvec;
+    if (dist <= margin) {
+      cdst[0] = dist;
+      for (int k = 0; k < 3; k++) cp[0][k] = pos[k] + vec[k] + axis[k] - n[k] * dist * 0.5f;
+      cnt = 1;
+      dist = dist0 - prjaxis + prjvec;
+      if (dist <= margin) {
+        cdst[cnt] = dist;
+        for (int k = 0; k < 3; k++) cp[cnt][k] = pos[k] + vec[k] - axis[k] - n[k] * dist * 0.5f;
+        cnt++;
+      }
+      float vec1[3];
+      cross(vec1, vec, axis);
+      const float s1 = radius * 0.8660254037844386f * rsqrtf(fmaxf(dot3(vec1, vec1), 1e-30f));
+      vec1[0] *= s1; vec1[1] *= s1; vec1[2] *= s1;
+      const float prjvec1 = dot3(vec1, n);
+      dist = dist0 + prjaxis - prjvec * 0.5f + prjvec1;
+      if (dist <= margin) {
+        cdst[cnt] = dist;
+        for (int k = 0; k < 3; k++) cp[cnt][k] = pos[k] + vec1[k] + axis[k] - vec[k] * 0.5f - n[k] * dist * 0.5f;
+        cnt++;
+      }
+      dist = dist0 + prjaxis - prjvec * 0.5f - prjvec1;
+      if (dist <= margin) {
+        cdst[cnt] = dist;
+        for (int k = 0; k < 3; k++) cp[cnt][k] = pos[k] - vec1[k] + axis[k] - vec[k] * 0.5f - n[k] * dist * 0.5f;
+        cnt++;
+      }
+    }
+  } else if (gt == CS_GEOM_BOX) {
+    qmul(gq, xq, R.g_quat);
+    q2m(mat, gq);
+    for (int i = 0; i < 8 && cnt < 4; i++) {
+      const float vx = (i & 1) ? R.g_size[0] : -R.g_size[0], vy = (i & 2) ? R.g_size[1] : -R.g_size[1], vz = (i & 4) ? R.g_size[2] : -R.g_size[2];
+      const float c[3] = {mat[0] * vx + mat[1] * vy + mat[2] * vz, mat[3] * vx + mat[4] * vy + mat[5] * vz, mat[6] * vx + mat[7] * vy + mat[8] * vz};
+      const float ld = dot3(n, c);
+      if (dist0 + ld > margin || ld > 0.f) continue;
+      const float dist = dist0 + ld;
+      cdst[cnt] = dist;
+      for (int k = 0; k < 3; k++) cp[cnt][k] = pos[k] + c[k] - n[k] * dist * 0.5f;
+      cnt++;
+    }
+  }
+  return cnt;
+}
+
+struct Terrain {  // heightfield geometry; (ox, oy) = world position of the local frame origin (the base's x, y)
+  const float* data;
+  int nrow, ncol;
+  float sx, sy, sz, gz;
+  double ox, oy, dx, dy;   // ox, oy already relative to the hfield centre: local x -> field x = x + ox
+};
+// collision triangle t of cell (r, c): {(r,c),(r+1,c),(r,c+1)} / {(r+1,c),(r,c+1),(r+1,c+1)} (prism strip order of
+// mjc_ConvexHField); P0 = first vertex, n = upward unit normal
+__device__ __forceinline__ void terrain_triangle(const Terrain& T, int r, int c, int t, float* P0, float* n) {
+  const int r0 = t ? r + 1 : r, c0 = c, r1 = t ? r : r + 1, c1 = t ? c + 1 : c, r2 = t ? r + 1 : r, c2 = c + 1;
+  const float z0 = T.sz * T.data[r0 * T.ncol + c0], z1 = T.sz * T.data[r1 * T.ncol + c1], z2 = T.sz * T.data[r2 * T.ncol + c2];
+  P0[0] = (float)(c0 * T.dx - (double)T.sx - T.ox); P0[1] = (float)(r0 * T.dy - (double)T.sy - T.oy); P0[2] = z0 + T.gz;
+  const float e1[3] = {(float)((c1 - c0) * T.dx), (float)((r1 - r0) * T.dy), z1 - z0}, e2[3] = {(float)((c2 - c0) * T.dx), (float)((r2 - r0) * T.dy), z2 - z0};
+  cross(n, e1, e2);
+  float s = rsqrtf(dot3(n, n));
+  if (n[2] < 0.f) s = -s;
+  n[0] *= s; n[1] *= s; n[2] *= s;
+}
+// is the world point over triangle t of cell (r, c)?  half-open footprint test in cell coordinates
+__device__ __forceinline__ bool terrain_footprint(const Terrain& T, int r, int c, int t, const float* p) {
+  const double u = ((double)p[0] + T.ox + (double)T.sx) / T.dx - (double)c, w = ((double)p[1] + T.oy + (double)T.sy) / T.dy - (double)r;
+  return u >= 0.0 && u < 1.0 && w >= 0.0 && w < 1.0 && ((t == 0) == (u + w <= 1.0));
+}
+// candidate cells under a bounding sphere (at most 4 x 4 around the centre); returns false when off the field
+__device__ __forceinline__ bool terrain_cells(const Terrain& T, const float* ctr, float rb, int& rmin, int& rmax, int& cmin, int& cmax) {
+  const double lx = (double)ctr[0] + T.ox, ly = (double)ctr[1] + T.oy;
+  if (fabs(lx) - rb > T.sx || fabs(ly) - rb > T.sy) return false;
+  cmin = (int)floor((lx - rb + T.sx) / T.dx); cmax = (int)floor((lx + rb + T.sx) / T.dx);
+  rmin = (int)floor((ly - rb + T.sy) / T.dy); rmax = (int)floor((ly + rb + T.sy) / T.dy);
+  const int cc = (int)floor((lx + T.sx) / T.dx), rc = (int)floor((ly + T.sy) / T.dy);
+  if (cmax - cmin > 3) { cmin = cc - 1; cmax = cc + 2; }
+  if (rmax - rmin > 3) { rmin = rc - 1; rmax = rc + 2; }
+  cmin = max(cmin, 0); rmin = max(rmin, 0); cmax = min(cmax, T.ncol - 2); rmax = min(rmax, T.nrow - 2);
+  return true;
+}
+// terrain elevation under (x, y) on the ray triangulation (mj_rayHfield: cell split along (r,c)-(r+1,c+1)); inside = on the field
+__device__ __forceinline__ float terrain_height(const Terrain& T, float x, float y, bool& inside) {  // (x, y) local
+  const double lx = (double)x + T.ox, ly = (double)y + T.oy;
+  inside = !(lx < -T.sx || lx > T.sx || ly < -T.sy || ly > T.sy);
+  if (!inside) return 0.f;
+  const double fx = (lx + T.sx) / T.dx, fy = (ly + T.sy) / T.dy;
+  int c = min(max((int)floor(fx), 0), T.ncol - 2), r = min(max((int)floor(fy), 0), T.nrow - 2);
+  const float u = (float)(fx - (double)c), v = (float)(fy - (double)r);
+  const float h00 = T.data[r * T.ncol + c], h01 = T.data[r * T.ncol + c + 1], h10 = T.data[(r + 1) * T.ncol + c], h11 = T.data[(r + 1) * T.ncol + c + 1];
+  const float hh = u >= v ? h00 + u * (h01 - h00) + v * (h11 - h01) : h00 + v * (h10 - h00) + u * (h11 - h10);
+  return T.gz + T.sz * hh;
+}
+
 // ------------------------------------------------------------------------------------------------ impedance (mj_makeImpedance)
 __device__ __forceinline__ float impedance(const float* solimp, float pos, float margin) {
   float d0 = fminf(MAXIMP, fmaxf(MINIMP, solimp[0])), d1 = fminf(MAXIMP, fmaxf(MINIMP, solimp[1]));
@@ -239,7 +367,7 @@ __device__ __forceinline__ float impedance(const float* solimp, float pos, float
 }
 
 // ------------------------------------------------------------------------------------------------ the kernel
-template <int NV, int NB, int RPL>
+template <int NV, int NB, int RPL, bool HF>   // HF: heightfield ground (false: plane); kept out of the flat kernels' register budget
 __global__ __launch_bounds__(64, RPL == 1 ? 4 : 2) void env_kernel(KArgs A) {
   using L = EnvLds<NV, NB, RPL>;
   constexpr int MAXROWS = L::ROWS;
@@ -354,7 +482,9 @@ __global__ __launch_bounds__(64, RPL == 1 ? 4 : 2) void env_kernel(KArgs A) {
             float xp[3], xq[4], anc[3] = {0.f, 0.f, 0.f}, ax[3] = {0.f, 0.f, 1.f};
             if (jt == CS_JNT_FREE) {
               const int qa = R.b_qadr;
-              for (int k = 0; k < 3; k++) xp[k] = S.qpos[qa + k];
+              // the step is invariant under horizontal translation except for terrain lookups: run it in a frame whose
+              // origin is under the base (fp32 keeps mm-level contact depths exact even 100 m from the world origin)
+              xp[0] = 0.f; xp[1] = 0.f; xp[2] = S.qpos[qa + 2];
               for (int k = 0; k < 4; k++) xq[k] = S.qpos[qa + 3 + k];
               qnorm(xq);
               for (int k = 0; k < 3; k++) { anc[k] = xp[k]; ax[k] = R.j_axis[k]; }
@@ -598,154 +728,145 @@ __global__ __launch_bounds__(64, RPL == 1 ? 4 : 2) void env_kernel(KArgs A) {
         }
       }
 
-      // =========================================================== collision: ground plane vs robot geoms (lane = geom)
+      // =========================================================== collision: ground (plane or heightfield) vs robot geoms
       int ncon = 0;
       {
         const LaneRec& R = dm.rec[ln];
-        float cp[4][3], cdst[4];
+        constexpr bool is_plane = !HF;
+        Terrain T;
+        T.data = A.hfield; T.nrow = dm.hfield_nrow; T.ncol = dm.hfield_ncol;
+        T.sx = dm.hfield_size[0]; T.sy = dm.hfield_size[1]; T.sz = dm.hfield_size[2]; T.gz = dm.ground_pos[2];
+        T.ox = (double)S.qpos[0] - (double)dm.ground_pos[0]; T.oy = (double)S.qpos[1] - (double)dm.ground_pos[1];
+        T.dx = is_plane ? 1.0 : 2.0 * (double)T.sx / (double)(T.ncol - 1); T.dy = is_plane ? 1.0 : 2.0 * (double)T.sy / (double)(T.nrow - 1);
+        float acp[4][3], anr[4][3], adst[4];   // this lane's (geom's) contacts
         int cnt = 0;
         bool mesh_near = false;
-        const float n[3] = {0.f, 0.f, 1.f};
-        const float gz = dm.ground_pos[2];
-        if (ln < ngeom && R.g_ground) {
-          const int b = R.g_body, gt = R.g_type;
-          float xq[4] = {S.xquat[b][0], S.xquat[b][1], S.xquat[b][2], S.xquat[b][3]};
-          const float margin = R.g_margin;
-          if (gt == CS_GEOM_MESH) {
-            float v[3];
-            qrot(v, xq, R.g_rcenter);
-            mesh_near = (S.xpos[b][2] + v[2] - gz - R.g_rbound) <= margin;
-          } else {
-            float v[3], pos[3], gq[4], mat[9];
-            qrot(v, xq, R.g_pos);
-            for (int k = 0; k < 3; k++) pos[k] = S.xpos[b][k] + v[k];
-            const float dist0 = pos[2] - gz;
-            if (gt == CS_GEOM_SPHERE) {
-              const float r = R.g_size[0];
-              if (dist0 <= margin + r) {
-                float dist = dist0 - r;
-                cdst[0] = dist;
-                cp[0][0] = pos[0]; cp[0][1] = pos[1]; cp[0][2] = pos[2] - (r + 0.5f * dist);
-                cnt = 1;
-              }
-            } else if (gt == CS_GEOM_CYLINDER) {  // mjc_PlaneCylinder
-              qmul(gq, xq, R.g_quat);
-              q2m(mat, gq);
-              const float radius = R.g_size[0], half = R.g_size[1];
-              float axis[3] = {mat[2], mat[5], mat[8]};
-              float prjaxis = axis[2];
-              if (prjaxis > 0.f) { axis[0] = -axis[0]; axis[1] = -axis[1]; axis[2] = -axis[2]; prjaxis = -prjaxis; }
-              float vec[3] = {axis[0] * prjaxis, axis[1] * prjaxis, axis[2] * prjaxis - 1.f};
-              float len = sqrtf(dot3(vec, vec));
-              if (len < 1e-12f) { vec[0] = mat[0] * radius; vec[1] = mat[3] * radius; vec[2] = mat[6] * radius; }
-              else { float s = radius / len; vec[0] *= s; vec[1] *= s; vec[2] *= s; }
-              const float prjvec = vec[2];
-              axis[0] *= half; axis[1] *= half; axis[2] *= half;
-              prjaxis *= half;
-              float dist = dist0 + prjaxis + prjvec;
-              if (dist <= margin) {
-                cdst[0] = dist;
-                for (int k = 0; k < 3; k++) cp[0][k] = pos[k] + vec[k] + axis[k] - n[k] * dist * 0.5f;
-                cnt = 1;
-                dist = dist0 - prjaxis + prjvec;
-                if (dist <= margin) {
-                  cdst[cnt] = dist;
-                  for (int k = 0; k < 3; k++) cp[cnt][k] = pos[k] + vec[k] - axis[k] - n[k] * dist * 0.5f;
-                  cnt++;
-                }
-                float vec1[3];
-                cross(vec1, vec, axis);
-                float s1 = radius * 0.8660254037844386f * rsqrtf(fmaxf(dot3(vec1, vec1), 1e-30f));
-                vec1[0] *= s1; vec1[1] *= s1; vec1[2] *= s1;
-                const float prjvec1 = vec1[2];
-                dist = dist0 + prjaxis - prjvec * 0.5f + prjvec1;
-                if (dist <= margin) {
-                  cdst[cnt] = dist;
-                  for (int k = 0; k < 3; k++) cp[cnt][k] = pos[k] + vec1[k] + axis[k] - vec[k] * 0.5f - n[k] * dist * 0.5f;
-                  cnt++;
-                }
-                dist = dist0 + prjaxis - prjvec * 0.5f - prjvec1;
-                if (dist <= margin) {
-                  cdst[cnt] = dist;
-                  for (int k = 0; k < 3; k++) cp[cnt][k] = pos[k] - vec1[k] + axis[k] - vec[k] * 0.5f - n[k] * dist * 0.5f;
-                  cnt++;
-                }
-              }
-            } else if (gt == CS_GEOM_BOX) {  // mjc_PlaneBox
-              qmul(gq, xq, R.g_quat);
-              q2m(mat, gq);
-              for (int i = 0; i < 8 && cnt < 4; i++) {
-                float vx = (i & 1) ? R.g_size[0] : -R.g_size[0], vy = (i & 2) ? R.g_size[1] : -R.g_size[1], vz = (i & 4) ? R.g_size[2] : -R.g_size[2];
-                float c[3] = {mat[0] * vx + mat[1] * vy + mat[2] * vz, mat[3] * vx + mat[4] * vy + mat[5] * vz, mat[6] * vx + mat[7] * vy + mat[8] * vz};
-                float ld = c[2];
-                if (dist0 + ld > margin || ld > 0.f) continue;
-                float dist = dist0 + ld;
-                cdst[cnt] = dist;
-                for (int k = 0; k < 3; k++) cp[cnt][k] = pos[k] + c[k] - n[k] * dist * 0.5f;
-                cnt++;
-              }
+        const float gpos[3] = {0.f, 0.f, T.gz};
+        const bool active = ln < ngeom && R.g_ground;
+        const int b = active ? R.g_body : 0, gt = active ? R.g_type : -1;
+        float xq[4] = {S.xquat[b][0], S.xquat[b][1], S.xquat[b][2], S.xquat[b][3]};
+        float xp[3] = {S.xpos[b][0], S.xpos[b][1], S.xpos[b][2]};
+        float ctr[3];
+        {
+          float v[3];
+          qrot(v, xq, R.g_rcenter);
+          for (int k = 0; k < 3; k++) ctr[k] = xp[k] + v[k];
+        }
+        const float margin = R.g_margin, rb = R.g_rbound;
+        if (is_plane) {
+          const float nz[3] = {0.f, 0.f, 1.f};
+          if (active && gt == CS_GEOM_MESH) mesh_near = (ctr[2] - T.gz - rb) <= margin;
+          else if (active) {
+            cnt = prim_plane(R, xq, xp, gpos, nz, margin, acp, adst);
+            for (int i = 0; i < cnt; i++) { anr[i][0] = 0.f; anr[i][1] = 0.f; anr[i][2] = 1.f; }
+          }
+        } else if (active) {
+          int rmin, rmax, cmin, cmax;
+          if (terrain_cells(T, ctr, rb, rmin, rmax, cmin, cmax)) {
+            if (gt == CS_GEOM_MESH) mesh_near = true;   // refined per triangle below
+            else {
+              for (int r = rmin; r <= rmax; r++)
+                for (int c = cmin; c <= cmax; c++)
+                  for (int t = 0; t < 2; t++) {
+                    if (cnt >= 4) continue;
+                    float P0[3], n[3];
+                    terrain_triangle(T, r, c, t, P0, n);
+                    if (n[0] * (ctr[0] - P0[0]) + n[1] * (ctr[1] - P0[1]) + n[2] * (ctr[2] - P0[2]) - rb > margin) continue;
+                    float cp[4][3], cdst[4];
+                    const int k4 = prim_plane(R, xq, xp, P0, n, margin, cp, cdst);
+                    for (int i = 0; i < k4; i++)
+                      if (cnt < 4 && terrain_footprint(T, r, c, t, cp[i])) {
+                        adst[cnt] = cdst[i];
+                        for (int k = 0; k < 3; k++) { acp[cnt][k] = cp[i][k]; anr[cnt][k] = n[k]; }
+                        cnt++;
+                      }
+                  }
             }
           }
         }
         // compaction in (geom, slot) order
         int off = 0, total = 0;
 #pragma unroll
-        for (int s = 0; s < 4; s++) {
-          unsigned long long mk = __ballot(cnt > s);
+        for (int s2 = 0; s2 < 4; s2++) {
+          unsigned long long mk = __ballot(cnt > s2);
           off += __popcll(mk & lanemask_lt(ln));
           total += __popcll(mk);
         }
-        for (int s = 0; s < cnt; s++) {
-          int slot = off + s;
+        for (int s2 = 0; s2 < cnt; s2++) {
+          const int slot = off + s2;
           if (slot < MC) {
-            S.cdist[slot] = cdst[s];
+            S.cdist[slot] = adst[s2];
             S.cgeom[slot] = ln;
-            for (int k = 0; k < 3; k++) { S.cpos[slot][k] = cp[s][k]; S.cnrm[slot][k] = n[k]; }
+            for (int k = 0; k < 3; k++) { S.cpos[slot][k] = acp[s2][k]; S.cnrm[slot][k] = anr[s2][k]; }
           }
         }
         ncon = total;
-        // convex meshes near the ground: all lanes scan the hull (mjc_PlaneConvex)
+        // convex meshes near the ground: all lanes scan the hull (mjc_PlaneConvex against the plane / each candidate triangle)
         unsigned long long mm = __ballot(mesh_near);
         while (mm) {
           const int g = __builtin_ctzll(mm);
           mm &= mm - 1;
           const LaneRec& G = dm.rec[g];
-          const int b = G.g_body, adr = G.g_hulladr, num = G.g_hullnum;
-          float xq[4] = {S.xquat[b][0], S.xquat[b][1], S.xquat[b][2], S.xquat[b][3]}, m[9];
-          q2m(m, xq);
-          const float lnz[3] = {m[6], m[7], m[8]};  // R^T n for n = +z
-          const float offz = S.xpos[b][2] - gz;
-          const float margin = G.g_margin;
-          float best = 3.0e38f;
-          int besti = 0x7fffffff;
-          for (int i = ln; i < num; i += 64) {
-            const float* v = A.hull_vert + 3 * (adr + i);
-            float dist = offz + lnz[0] * v[0] + lnz[1] * v[1] + lnz[2] * v[2];
-            if (dist < best) { best = dist; besti = i; }
+          const int gb = G.g_body, adr = G.g_hulladr, num = G.g_hullnum;
+          float gq[4] = {S.xquat[gb][0], S.xquat[gb][1], S.xquat[gb][2], S.xquat[gb][3]}, m[9];
+          q2m(m, gq);
+          const float gxp[3] = {S.xpos[gb][0], S.xpos[gb][1], S.xpos[gb][2]};
+          const float gmargin = G.g_margin, grb = G.g_rbound;
+          float gctr[3];
+          {
+            float v[3];
+            qrot(v, gq, G.g_rcenter);
+            for (int k = 0; k < 3; k++) gctr[k] = gxp[k] + v[k];
           }
-          const float bmin = wave_min(best);
-          if (!(bmin <= margin)) continue;
-          int bi = (best == bmin) ? besti : 0x7fffffff;  // lowest vertex index among ties, like a sequential scan
+          int rmin = 0, rmax = 0, cmin = 0, cmax = 0;
+          if (!is_plane && !terrain_cells(T, gctr, grb, rmin, rmax, cmin, cmax)) continue;
+          int gadded = 0;
+          for (int r = rmin; r <= rmax; r++)
+            for (int c = cmin; c <= cmax; c++)
+              for (int t = 0; t < (is_plane ? 1 : 2); t++) {
+                if (gadded >= 4) continue;
+                float P0[3] = {0.f, 0.f, T.gz}, n[3] = {0.f, 0.f, 1.f};
+                if (!is_plane) {
+                  terrain_triangle(T, r, c, t, P0, n);
+                  if (n[0] * (gctr[0] - P0[0]) + n[1] * (gctr[1] - P0[1]) + n[2] * (gctr[2] - P0[2]) - grb > gmargin) continue;
+                }
+                const float lnv[3] = {m[0] * n[0] + m[3] * n[1] + m[6] * n[2], m[1] * n[0] + m[4] * n[1] + m[7] * n[2], m[2] * n[0] + m[5] * n[1] + m[8] * n[2]};  // R^T n
+                const float offn = n[0] * (gxp[0] - P0[0]) + n[1] * (gxp[1] - P0[1]) + n[2] * (gxp[2] - P0[2]);
+                float best = 3.0e38f;
+                int besti = 0x7fffffff;
+                for (int i = ln; i < num; i += 64) {
+                  const float* v = A.hull_vert + 3 * (adr + i);
+                  const float dist = offn + lnv[0] * v[0] + lnv[1] * v[1] + lnv[2] * v[2];
+                  if (dist < best) { best = dist; besti = i; }
+                }
+                const float bmin = wave_min(best);
+                if (!(bmin <= gmargin)) continue;
+                int bi = (best == bmin) ? besti : 0x7fffffff;  // lowest vertex index among ties, like a sequential scan
 #pragma unroll
-          for (int o = 32; o > 0; o >>= 1) bi = min(bi, __shfl_xor(bi, o, 64));
-          int added = 0;
-          for (int pass = 0; pass < 2; pass++) {
-            const int lo = pass ? A.hull_adr[adr + bi] : 0, hi = pass ? A.hull_adr[adr + bi + 1] : 1;
-            for (int e = lo; e < hi && added < 4; e++) {
-              const int i = pass ? A.hull_nbr[e] : bi;
-              const float* v = A.hull_vert + 3 * (adr + i);
-              float dist = offz + lnz[0] * v[0] + lnz[1] * v[1] + lnz[2] * v[2];
-              if (dist > margin) continue;
-              if (ncon < MC && ln == 0) {
-                float w[3] = {m[0] * v[0] + m[1] * v[1] + m[2] * v[2], m[3] * v[0] + m[4] * v[1] + m[5] * v[2], m[6] * v[0] + m[7] * v[1] + m[8] * v[2]};
-                S.cdist[ncon] = dist;
-                S.cgeom[ncon] = g;
-                for (int k = 0; k < 3; k++) { S.cpos[ncon][k] = S.xpos[b][k] + w[k] - n[k] * dist * 0.5f; S.cnrm[ncon][k] = n[k]; }
+                for (int o = 32; o > 0; o >>= 1) bi = min(bi, __shfl_xor(bi, o, 64));
+                int added = 0;
+                for (int pass = 0; pass < 2; pass++) {
+                  const int lo = pass ? A.hull_adr[adr + bi] : 0, hi = pass ? A.hull_adr[adr + bi + 1] : 1;
+                  for (int e = lo; e < hi && added < 4; e++) {
+                    const int i = pass ? A.hull_nbr[e] : bi;
+                    const float* v = A.hull_vert + 3 * (adr + i);
+                    const float dist = offn + lnv[0] * v[0] + lnv[1] * v[1] + lnv[2] * v[2];
+                    if (dist > gmargin) continue;
+                    const float w[3] = {m[0] * v[0] + m[1] * v[1] + m[2] * v[2], m[3] * v[0] + m[4] * v[1] + m[5] * v[2], m[6] * v[0] + m[7] * v[1] + m[8] * v[2]};
+                    const float cpw[3] = {gxp[0] + w[0] - n[0] * dist * 0.5f, gxp[1] + w[1] - n[1] * dist * 0.5f, gxp[2] + w[2] - n[2] * dist * 0.5f};
+                    added++;   // the plane routine's own 4-contact budget (as in the oracle: filtered afterwards)
+                    if (!is_plane && !terrain_footprint(T, r, c, t, cpw)) continue;
+                    if (gadded >= 4) continue;
+                    if (ncon < MC && ln == 0) {
+                      S.cdist[ncon] = dist;
+                      S.cgeom[ncon] = g;
+                      for (int k = 0; k < 3; k++) { S.cpos[ncon][k] = cpw[k]; S.cnrm[ncon][k] = n[k]; }
+                    }
+                    ncon++;
+                    gadded++;
+                  }
+                }
               }
-              ncon++;
-              added++;
-            }
-          }
         }
       }
 
@@ -1300,6 +1421,26 @@ __global__ __launch_bounds__(64, RPL == 1 ? 4 : 2) void env_kernel(KArgs A) {
         case CS_OBS_LIN_VEL: val = idx == 0 ? s_vel[0] : (idx == 1 ? s_vel[1] : s_vel[2]); break;
         case CS_OBS_PROJ_GRAVITY: val = idx == 0 ? pg[0] : (idx == 1 ? pg[1] : pg[2]); break;
         case CS_OBS_LAST_ACTION: val = S.act[idx]; break;
+        case CS_OBS_HEIGHT_MAP: if (HF) {
+          // get_height_map (utils/mujoco_utils.py:98-189): sample (i, j) = idx / res_x, idx % res_x of the window in the base
+          // frame rotated by the raw base quaternion; vertical ray from 10 m above; value = robot_z - terrain_z
+          const int rx = ob.hm_res_x, ry = ob.hm_res_y, i = idx / rx, j = idx - i * rx;
+          const float xr = rx > 1 ? -0.5f * ob.hm_size_x + ob.hm_size_x * (float)j / (float)(rx - 1) : -0.5f * ob.hm_size_x;
+          const float yr = ry > 1 ? -0.5f * ob.hm_size_y + ob.hm_size_y * (float)i / (float)(ry - 1) : -0.5f * ob.hm_size_y;
+          const float qw = S.qpos[3], qx = S.qpos[4], qy = S.qpos[5], qz = S.qpos[6];
+          const float wx = (1.f - 2.f * qy * qy - 2.f * qz * qz) * xr + (2.f * qx * qy - 2.f * qz * qw) * yr;   // relative to the base
+          const float wy = (2.f * qx * qy + 2.f * qz * qw) * xr + (1.f - 2.f * qx * qx - 2.f * qz * qz) * yr;
+          const float wz = S.qpos[2] + (2.f * qx * qz - 2.f * qy * qw) * xr + (2.f * qy * qz + 2.f * qx * qw) * yr;
+          Terrain T;
+          T.data = A.hfield; T.nrow = dm.hfield_nrow; T.ncol = dm.hfield_ncol;
+          T.sx = dm.hfield_size[0]; T.sy = dm.hfield_size[1]; T.sz = dm.hfield_size[2]; T.gz = dm.ground_pos[2];
+          T.ox = (double)S.qpos[0] - (double)dm.ground_pos[0]; T.oy = (double)S.qpos[1] - (double)dm.ground_pos[1];
+          T.dx = 2.0 * (double)T.sx / (double)(T.ncol - 1); T.dy = 2.0 * (double)T.sy / (double)(T.nrow - 1);
+          bool inside = false;
+          const float hz = terrain_height(T, wx, wy, inside);
+          val = (inside && hz <= wz + 10.f) ? S.qpos[2] - hz : S.qpos[2] + dm.heightmap_miss;
+          break;
+        }
         default: val = 0.f; break;
       }
       if (ob.noise_enabled && f != CS_OBS_LAST_ACTION && f != CS_OBS_COMMAND) {

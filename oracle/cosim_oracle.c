@@ -533,29 +533,69 @@ static double hfield_height(const oracle_data* d, double x, double y, int* insid
   return m->ground_pos[2] + sz * h;
 }
 
+/* Heightfield narrowphase.  NOT a restatement of mjc_ConvexHField: MuJoCo runs libccd's MPR between the geom and every
+ * triangular prism under the geom's bounding box (one contact per penetrated prism); this build uses a cheaper, fully
+ * specified rule: for every collision triangle {(r,c),(r+1,c),(r,c+1)} / {(r+1,c),(r,c+1),(r+1,c+1)} (the prism strip
+ * order of mjc_ConvexHField) within the geom's bounding-sphere footprint (at most 4 x 4 cells around the centre), run the
+ * *plane* routine of the geom type against the triangle's supporting plane and keep the contacts whose position lies over
+ * that triangle (half-open footprint test in cell coordinates, so triangles tile without duplicates).  On a locally flat
+ * terrain this reproduces the plane contacts exactly.  At most 4 contacts per geom, in (r, c, triangle) order.
+ * The HIP engine implements the same rule. */
 static void hfield_collide(oracle_data* d, int g) {
-  /* Ground-as-hfield contact for the primitive set of the robots: the geom's lowest points (same candidate points the
-     plane routines use) are tested against the local terrain triangle; the contact normal is that triangle's normal.
-     This is the plane routine applied per candidate point against the tangent plane of the terrain under it. */
   const cosim_model_t* m = &d->m;
-  double pos[3], mat[9];
-  geom_pose(d, g, pos, mat);
+  int b = m->geom_bodyid[g];
+  int nr = m->hfield_nrow, nc = m->hfield_ncol;
+  double sx = m->hfield_size[0], sy = m->hfield_size[1], sz = m->hfield_size[2];
   double margin = fmax(m->ground_margin, m->geom_margin[g]);
-  int inside;
-  const double eps = 1e-4;
-  double h0 = hfield_height(d, pos[0], pos[1], &inside);
-  if (!inside) return;
-  double hx = hfield_height(d, pos[0] + eps, pos[1], &inside), hy = hfield_height(d, pos[0], pos[1] + eps, &inside);
-  double n[3] = {-(hx - h0) / eps, -(hy - h0) / eps, 1};
-  normalize3(n);
-  double ppos[3] = {pos[0], pos[1], h0};
-  switch (m->geom_type[g]) {
-    case CS_GEOM_SPHERE: plane_sphere(d, g, ppos, n, margin); break;
-    case CS_GEOM_CYLINDER: plane_cylinder(d, g, ppos, n, margin); break;
-    case CS_GEOM_BOX: plane_box(d, g, ppos, n, margin); break;
-    case CS_GEOM_MESH: plane_mesh(d, g, ppos, n, margin); break;
-    default: break;
-  }
+  double ctr[3], v[3];
+  mul_mat_vec3(v, d->xmat[b], m->geom_rcenter[g]);
+  for (int k = 0; k < 3; k++) ctr[k] = d->xpos[b][k] + v[k] - m->ground_pos[k];
+  double rb = m->geom_rbound[g];
+  if (fabs(ctr[0]) - rb > sx || fabs(ctr[1]) - rb > sy) return;
+  double dx = 2 * sx / (nc - 1), dy = 2 * sy / (nr - 1);
+  int cmin = (int)floor((ctr[0] - rb + sx) / dx), cmax = (int)floor((ctr[0] + rb + sx) / dx);
+  int rmin = (int)floor((ctr[1] - rb + sy) / dy), rmax = (int)floor((ctr[1] + rb + sy) / dy);
+  int cc = (int)floor((ctr[0] + sx) / dx), rc = (int)floor((ctr[1] + sy) / dy);
+  if (cmax - cmin > 3) { cmin = cc - 1; cmax = cc + 2; }
+  if (rmax - rmin > 3) { rmin = rc - 1; rmax = rc + 2; }
+  if (cmin < 0) cmin = 0;
+  if (rmin < 0) rmin = 0;
+  if (cmax > nc - 2) cmax = nc - 2;
+  if (rmax > nr - 2) rmax = nr - 2;
+  int first = d->ncon;
+  for (int r = rmin; r <= rmax; r++)
+    for (int c = cmin; c <= cmax; c++)
+      for (int t = 0; t < 2; t++) {
+        if (d->ncon - first >= 4) return;
+        int ri[3] = {t ? r + 1 : r, t ? r : r + 1, t ? r + 1 : r}, ci[3] = {c, t ? c + 1 : c, c + 1};
+        double P[3][3];
+        for (int q = 0; q < 3; q++) {
+          P[q][0] = ci[q] * dx - sx + m->ground_pos[0]; P[q][1] = ri[q] * dy - sy + m->ground_pos[1];
+          P[q][2] = sz * d->hfield[ri[q] * nc + ci[q]] + m->ground_pos[2];
+        }
+        double e1[3], e2[3], n[3];
+        for (int k = 0; k < 3; k++) { e1[k] = P[1][k] - P[0][k]; e2[k] = P[2][k] - P[0][k]; }
+        cross3(n, e1, e2);
+        normalize3(n);
+        if (n[2] < 0) { n[0] = -n[0]; n[1] = -n[1]; n[2] = -n[2]; }
+        double dc[3] = {ctr[0] + m->ground_pos[0] - P[0][0], ctr[1] + m->ground_pos[1] - P[0][1], ctr[2] + m->ground_pos[2] - P[0][2]};
+        if (dot3(n, dc) - rb > margin) continue;
+        int before = d->ncon;
+        switch (m->geom_type[g]) {
+          case CS_GEOM_SPHERE: plane_sphere(d, g, P[0], n, margin); break;
+          case CS_GEOM_CYLINDER: plane_cylinder(d, g, P[0], n, margin); break;
+          case CS_GEOM_BOX: plane_box(d, g, P[0], n, margin); break;
+          case CS_GEOM_MESH: plane_mesh(d, g, P[0], n, margin); break;
+          default: break;
+        }
+        int keep = before;
+        for (int i = before; i < d->ncon; i++) { /* footprint filter in cell coordinates */
+          double u = (d->con[i].pos[0] - m->ground_pos[0] + sx) / dx - c, w = (d->con[i].pos[1] - m->ground_pos[1] + sy) / dy - r;
+          int in = u >= 0 && u < 1 && w >= 0 && w < 1 && ((t == 0) == (u + w <= 1));
+          if (in && keep - first < 4) d->con[keep++] = d->con[i];
+        }
+        d->ncon = keep;
+      }
 }
 
 /* vertical ray from (x, y, z0) along -z; returns distance or -1 (reference utils/mujoco_utils.py:169 mj_rayHfield) */

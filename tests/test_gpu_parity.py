@@ -335,3 +335,71 @@ def test_other_robots_one_control_step_replay_flat(env_id, steps):
         # cfrc_ext termination (flamingo_p_v3.py:225-233): agree except within round-off of the 1.0 threshold
         assert (got[ok] == R["term"][ok]).mean() > 0.9
     env.close()
+
+
+@pytest.mark.parametrize("env_id,terrain,hm", [("flamingo_light_v1", "rocky_hard", False), ("w4_p_v2", "rocky_hard", True),
+                                                ("flamingo_light_v1", "slope_hard", False)])
+def test_heightfield_terrain_replay_and_height_map(env_id, terrain, hm):
+    """Heightfield ground (config 3: w4_p_v2 on rocky_hard): robots dropped at scattered places of the terrain; one-step
+    replay against the oracle, and the height-map observation against the oracle's vertical ray (mj_rayHfield)."""
+    import torch
+    from cosim_amd.batched_env import BatchedEnv
+    from cosim_amd.compile import compile_model
+    from cosim_amd.config import PARITY_RANDOM, make_config
+    from cosim_amd.model import get_field
+    from oracle.oracle import Oracle
+    cfg = make_config(env_id, terrain=terrain, random=PARITY_RANDOM, height_map=hm)
+    cm = compile_model(cfg)
+    b = cm.blob
+    assert b.ground_type == 1 and cm.hfield.shape == (512, 512)
+    rng = np.random.default_rng(11)
+    o = Oracle(cm)
+    q0 = np.array(get_field(b, "init_qpos")[:b.nq])
+    R = dict(qpos=[], qvel=[], warm=[], act=[], qpos1=[], qvel1=[], ncon=[], tilt=[])
+    for spot in range(12):
+        q = q0.copy()
+        q[0:2] = rng.uniform(-100, 100, size=2)
+        yaw = rng.uniform(-np.pi, np.pi)
+        q[3:7] = [np.cos(yaw / 2), 0, 0, np.sin(yaw / 2)]
+        q[2] = q0[2] + (10.0 - o.ray_down(q[0], q[1], 10.0)) + 0.02        # spawn height above the local terrain
+        o.reset(q)
+        for t in range(40):
+            a = np.clip(0.1 * rng.normal(size=b.nu), -1, 1)
+            R["qpos"].append(o.qpos.copy()); R["qvel"].append(o.qvel.copy()); R["warm"].append(o.qacc_warmstart.copy()); R["act"].append(a)
+            o.control_step(a)
+            R["qpos1"].append(o.qpos.copy()); R["qvel1"].append(o.qvel.copy()); R["ncon"].append(o.ncon)
+            R["tilt"].append(float(np.abs(o.contacts()[:, 4:6]).max()) if o.ncon else 0.0)
+    R = {k: np.array(v) for k, v in R.items()}
+    n = len(R["qpos"])
+    assert R["ncon"].max() >= 4 and R["tilt"].max() > 0.02            # the samples really sit on sloped triangles
+    env = BatchedEnv(cfg, num_envs=n, auto_reset=False, compiled=cm)
+    env.reset()
+    env.set_state(R["qpos"], R["qvel"], R["warm"])
+    state, _, _, _ = env.step(torch.tensor(R["act"], dtype=torch.float32, device=env.device))
+    d = env.get_data()
+    qp, qv = d.qpos.cpu().numpy().astype(np.float64), d.qvel.cpu().numpy().astype(np.float64)
+    ok = R["ncon"] <= (12 if b.nv == 18 else 16)
+    ep = np.abs(qp - R["qpos1"])[ok].max(axis=1)
+    ev = np.abs(qv - R["qvel1"])[ok].max(axis=1)
+    # positions of order 100 m in fp32: 1e-5 m resolution; contact onsets at triangle edges can flip for a few samples
+    assert np.quantile(ep, 0.95) < 2e-4 and np.quantile(ev, 0.95) < 2e-2, (np.quantile(ep, 0.95), np.quantile(ev, 0.95), ep.max(), ev.max())
+    if hm:
+        ob = cfg["observation"]["height_map"]
+        rx, ry = ob["res_x"], ob["res_y"]
+        got = state[:, -rx * ry:].cpu().numpy().astype(np.float64)
+        for e in range(0, n, 37):
+            q = qp[e]
+            w, x, y, z = q[3:7]
+            Rm = np.array([[1 - 2 * y * y - 2 * z * z, 2 * x * y - 2 * z * w, 2 * x * z + 2 * y * w],
+                           [2 * x * y + 2 * z * w, 1 - 2 * x * x - 2 * z * z, 2 * y * z - 2 * x * w],
+                           [2 * x * z - 2 * y * w, 2 * y * z + 2 * x * w, 1 - 2 * x * x - 2 * y * y]])
+            xs = np.linspace(-ob["size_x"] / 2, ob["size_x"] / 2, rx)
+            ys = np.linspace(-ob["size_y"] / 2, ob["size_y"] / 2, ry)
+            exp = np.zeros((ry, rx))
+            for i in range(ry):
+                for j in range(rx):
+                    P = q[0:3] + Rm @ np.array([xs[j], ys[i], 0.0])
+                    dist = o.ray_down(P[0], P[1], P[2] + 10.0)
+                    exp[i, j] = q[2] - (P[2] + 10.0 - dist) if dist >= 0 else q[2] + 1.0
+            np.testing.assert_allclose(got[e], exp.ravel(), atol=2e-4)      # row-major i * res_x + j, robot_z - terrain_z
+    env.close()
