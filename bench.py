@@ -30,9 +30,20 @@ if ROOT not in sys.path:
 
 ENVS_PER_GPU = 4096
 ROBOT = "flamingo_light_v1"
-# B_alg = 4 [2 (nq + nv) + 3 nu + 2 state_dim + 2 nv] bytes per env-step
-B_ALG = {"flamingo_light_v1": 4 * (2 * (19 + 18) + 3 * 4 + 2 * 52 + 2 * 18)}   # 904
 HBM_PEAK_GBS = 8000.0
+# name -> (robot, terrain, height_map, envs per GPU).  The default ("light_flat") is BASELINE.json configs[1], the
+# configuration the metric is quoted on; the others are the remaining BASELINE configs, selectable for DESIGN.md numbers.
+WORKLOADS = {
+    "light_flat": ("flamingo_light_v1", "flat", False, 4096),
+    "w4_rocky": ("w4_p_v2", "rocky_hard", True, 4096),            # configs[2]
+    "p_v3_flat": ("flamingo_p_v3", "flat", False, 4096),          # configs[3] per-GPU shard (flat; its terrain is not named)
+    "humanoid_flat": ("humanoid_p_v0", "flat", False, 1024),      # configs[4] per-GPU shard on flat (stairs need more rows)
+}
+
+
+def b_alg(nq, nv, nu, state_dim):
+    """B_alg = 4 [2 (nq + nv) + 3 nu + 2 state_dim + 2 nv] bytes per env-step."""
+    return 4 * (2 * (nq + nv) + 3 * nu + 2 * state_dim + 2 * nv)
 
 
 def synthetic_actions(n_envs, env_id0, steps, nu, device):
@@ -84,7 +95,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1000)
     ap.add_argument("--warmup", type=int, default=100)
-    ap.add_argument("--envs-per-gpu", type=int, default=ENVS_PER_GPU)
+    ap.add_argument("--envs-per-gpu", type=int, default=0)
+    ap.add_argument("--workload", default="light_flat", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -101,10 +113,11 @@ def main():
     rank, world = init_from_env("nccl")
     local = int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local)
-    n = args.envs_per_gpu
+    robot, terrain, hmap, n_default = WORKLOADS[args.workload]
+    n = args.envs_per_gpu or n_default
     env_id0 = rank * n
 
-    cfg = make_config(ROBOT, terrain="flat", num_envs=n, seed=1234)
+    cfg = make_config(robot, terrain=terrain, num_envs=n, seed=1234, height_map=hmap)
     env = BatchedEnv(cfg, num_envs=n, device=local, seed=1234, auto_reset=True, env_id0=env_id0, gain_noise=0.1)
     nu = env.action_dim
     total_steps = args.warmup + args.steps
@@ -144,13 +157,13 @@ def main():
 
     if rank == 0:
         value = world * n * args.steps / dt
-        b_alg = B_ALG[ROBOT]
-        achieved = b_alg * n / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
+        balg = b_alg(env.nq, env.nv, nu, env.state_dim)
+        achieved = balg * n / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
         line = {
-            "metric": "env-steps/sec (whole node), flamingo_light_v1 xN envs", "value": value, "unit": "env-steps/s",
+            "metric": f"env-steps/sec (whole node), {robot} xN envs", "value": value, "unit": "env-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{ROBOT} x {n} envs per GPU, flat terrain, precision medium (4 x 5 ms substeps), "
+            "config": {"workload": f"{robot} x {n} envs per GPU, {terrain} terrain, precision medium (4 x 5 ms substeps), "
                                    "GUI-default domain randomisation + sensor noise low, sinusoid actions, auto-reset",
                        "envs_per_gpu": n, "global_envs": world * n, "substeps_per_s": value * 4, "parallelism": f"shard{world}",
                        "finite": finite, "fleet_action_diff_RMSE": fleet["action_diff_RMSE"]["mean"],
@@ -159,8 +172,8 @@ def main():
                        "nan_resets": st["nan_resets"]},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "cosim::env_kernel<18,14>", "kernel_ms": kernel_ms, "launches": launches,
-                         "algorithmic_bytes_per_env_step": b_alg,
+                         "kernel": f"cosim::env_kernel<{env.nv},{env.cm.blob.nbody},...>", "kernel_ms": kernel_ms, "launches": launches,
+                         "algorithmic_bytes_per_env_step": balg,
                          "note": "latency/VALU-bound small-state solver; HBM sees only the compulsory state traffic (SURVEY §8d)"},
         }
         if world == 1 and not args.no_cpu_baseline:

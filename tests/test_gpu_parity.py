@@ -403,3 +403,33 @@ def test_heightfield_terrain_replay_and_height_map(env_id, terrain, hm):
                     exp[i, j] = q[2] - (P[2] + 10.0 - dist) if dist >= 0 else q[2] + 1.0
             np.testing.assert_allclose(got[e], exp.ravel(), atol=2e-4)      # row-major i * res_x + j, robot_z - terrain_z
     env.close()
+
+
+def test_headless_runner_feeds_a_reporter_like_sink():
+    """Row T of SURVEY §8a: the Tester loop, headless and batched; one env's info stream has the Reporter contract."""
+    from cosim_amd.batched_env import BatchedEnv
+    from cosim_amd.config import make_config
+    from cosim_amd.runner import Runner, SinusoidPolicy
+
+    class Sink:                                  # core/reporter.py:210-218 stores every info value per key
+        def __init__(self):
+            self.history = {}
+
+        def write_info(self, info):
+            for k, v in info.items():
+                self.history.setdefault(k, []).append(v)
+
+    cfg = make_config("flamingo_light_v1", max_duration=0.4)
+    env = BatchedEnv(cfg, num_envs=8, auto_reset=False)
+    sink = Sink()
+    r = Runner(env, SinusoidPolicy(8, 4, env.device), reporter=sink, report_env=3)
+    r.update_command(0, 0.5)
+    r.activate_push_event([0.2, 0.0, 0.0])
+    n = r.test()
+    assert n == 20                                # int(0.4 * 50): all envs truncate together
+    h = sink.history
+    assert set(h) >= {"dt", "action", "action_diff_RMSE", "torque", "lin_vel_x", "lin_vel_y", "ang_vel_yaw", "set_points",
+                      "state", "user_command_0"}
+    assert len(h["torque"]) == 20 and h["torque"][0].shape == (4,) and len(h["set_points"][0]) == len(h["state"][0])
+    assert h["user_command_0"][0] == pytest.approx(0.5) and isinstance(h["action_diff_RMSE"][0], float)
+    env.close()
