@@ -362,6 +362,7 @@ def compile_model(config: dict, model_path: Optional[str] = None) -> CompiledMod
     hv, hadr, hnbr = [], [0], []
     g_hulladr, g_hullnum = np.zeros(ng, dtype=np.int32), np.zeros(ng, dtype=np.int32)
     g_rbound, g_rcenter = np.zeros(ng), np.zeros((ng, 3))
+    g_aabb = np.zeros((ng, 6))
     for i, g in enumerate(rgeoms):
         rot = quat_to_mat(_normalize(g["quat"]))
         if g["type"] == "mesh":
@@ -376,6 +377,8 @@ def compile_model(config: dict, model_path: Optional[str] = None) -> CompiledMod
             ctr = 0.5 * (vb.astype(np.float64).min(0) + vb.astype(np.float64).max(0))
             g_rcenter[i] = ctr
             g_rbound[i] = np.linalg.norm(vb.astype(np.float64) - ctr, axis=1).max()
+            g_aabb[i, :3] = ctr
+            g_aabb[i, 3:] = 0.5 * (vb.astype(np.float64).max(0) - vb.astype(np.float64).min(0))
         else:
             g_rcenter[i] = g["pos"]
             s = g["size"]
@@ -389,6 +392,8 @@ def compile_model(config: dict, model_path: Optional[str] = None) -> CompiledMod
                 g_rbound[i] = s[0] + s[1]
             else:
                 raise ValueError(f"collision geom type '{g['type']}' not supported")
+            g_aabb[i, :3] = g["pos"]
+            g_aabb[i, 3:] = g_rbound[i]
 
     def can_collide(a, b):
         return bool((a["contype"] & b["conaffinity"]) or (b["contype"] & a["conaffinity"]))
@@ -494,6 +499,7 @@ def compile_model(config: dict, model_path: Optional[str] = None) -> CompiledMod
         sf("geom_gap", np.array([g["gap"] for g in rgeoms]))
         sf("geom_rbound", g_rbound)
         sf("geom_rcenter", g_rcenter)
+        sf("geom_aabb", g_aabb)
     if len(pairs) > DEFINES["CS_MAXPAIR"]:
         raise ValueError(f"{len(pairs)} self-collision geom pairs exceed the blob capacity")
     if pairs:

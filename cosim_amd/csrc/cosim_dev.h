@@ -47,7 +47,7 @@ struct LaneRec {
   // ---- equality connect (index = equality id)
   int e_body1, e_body2;
   float e_anchor1[3], e_anchor2[3], e_solref[2], e_solimp[5];
-  int pad[3];
+  float g_half[3];  // half-extents of the body-frame box around the geom (centre = g_rcenter)
 };
 static_assert(sizeof(LaneRec) == 512, "LaneRec must stay 512 bytes (immediate-offset addressing)");
 
@@ -83,6 +83,7 @@ struct DevObs {
   unsigned char el_interval[MAXFRAME];
   float el_scale[MAXFRAME];
   float noise_mean[8], noise_std[8], noise_lower[8], noise_upper[8];
+  float noise_ca[8], noise_cb[8];  // Phi((lower - mean) / std), Phi((upper - mean) / std): constants of the inverse-CDF sampler
 };
 
 // per-env HBM record layouts (float offsets)

@@ -41,6 +41,7 @@ struct cosim_engine {
   int64_t env_id0 = 0;
   float tol32 = 1e-6f;
   int max_newton = 50;
+  int max_ls = 24;
   // timing
   bool timing = false;
   std::vector<hipEvent_t> ev;  // event pairs (start, stop) of timed launches not yet read back
@@ -48,12 +49,17 @@ struct cosim_engine {
   double t_accum_ms = 0.0;
   int t_launches = 0;
   void (*launch)(cosim_engine*, const KArgs&, int grid, hipStream_t) = nullptr;
+  void (*launch_prof)(cosim_engine*, const KArgs&, int grid, hipStream_t) = nullptr;  // diagnostic build (light_v1 flat only)
   int lds_bytes = 0;
 };
 
 template <int NV, int NB, int RPL, bool HF>
 static void launch_t(cosim_engine* e, const KArgs& a, int grid, hipStream_t s) {
   hipLaunchKernelGGL((env_kernel<NV, NB, RPL, HF>), dim3(grid), dim3(64), 0, s, a);
+}
+template <int NV, int NB, int RPL>
+static void launch_prof_t(cosim_engine* e, const KArgs& a, int grid, hipStream_t s) {
+  hipLaunchKernelGGL((env_kernel<NV, NB, RPL, false, true>), dim3(grid), dim3(64), 0, s, a);
 }
 template <int NV, int NB, int RPL>
 static void select_t(cosim_engine* e, bool hf) {
@@ -142,6 +148,8 @@ static int build_dev_model(cosim_engine* e) {
     for (int k = 0; k < 3; k++) { r.g_pos[k] = (float)m.geom_pos[g][k]; r.g_size[k] = (float)m.geom_size[g][k]; r.g_rcenter[k] = (float)m.geom_rcenter[g][k]; }
     for (int k = 0; k < 4; k++) r.g_quat[k] = (float)m.geom_quat[g][k];
     r.g_rbound = (float)m.geom_rbound[g];
+    for (int k = 0; k < 3; k++) r.g_half[k] = (float)m.geom_aabb[g][3 + k];
+    for (int k = 0; k < 3; k++) if (fabs(m.geom_aabb[g][k] - m.geom_rcenter[g][k]) > 1e-12) return fail(COSIM_EINVAL, "geom_aabb centre must equal geom_rcenter");
     // mj_contactParam with equal priorities: solmix-weighted solref/solimp, margins by max
     double s1 = m.ground_solmix, s2 = m.geom_solmix[g], mix;
     if (s1 >= 1e-15 && s2 >= 1e-15) mix = s1 / (s1 + s2);
@@ -196,7 +204,12 @@ static int build_dev_obs(cosim_engine* e) {
   o.action_delay_prob = c.action_delay_prob; o.init_noise = c.init_noise;
   for (int i = 0; i < CS_MAXCMD; i++) o.command_scales[i] = c.command_scales[i];
   o.hm_res_x = c.hm_res_x; o.hm_res_y = c.hm_res_y; o.hm_size_x = c.hm_size_x; o.hm_size_y = c.hm_size_y;
-  for (int f = 0; f < 8; f++) { o.noise_mean[f] = c.noise_mean[f]; o.noise_std[f] = c.noise_std[f]; o.noise_lower[f] = c.noise_lower[f]; o.noise_upper[f] = c.noise_upper[f]; }
+  for (int f = 0; f < 8; f++) {
+    o.noise_mean[f] = c.noise_mean[f]; o.noise_std[f] = c.noise_std[f]; o.noise_lower[f] = c.noise_lower[f]; o.noise_upper[f] = c.noise_upper[f];
+    const double sd = c.noise_std[f] > 0 ? c.noise_std[f] : 1.0;
+    o.noise_ca[f] = (float)(0.5 * erfc(-((double)c.noise_lower[f] - c.noise_mean[f]) / sd / sqrt(2.0)));
+    o.noise_cb[f] = (float)(0.5 * erfc(-((double)c.noise_upper[f] - c.noise_mean[f]) / sd / sqrt(2.0)));
+  }
   int el = 0;
   for (int pass = 0; pass < 2; pass++) {
     const int* list = pass ? c.non_stacked_field : c.stacked_field;
@@ -295,7 +308,7 @@ int cosim_create(const cosim_model_t* model, const float* hull_vert, const int* 
   const int nv = model->nv, nb = model->nbody;
   // kernel instantiations: (nv, nbody) of the four cosim robots; RPL = constraint rows per lane
   const bool hf = model->ground_type == CS_GEOM_HFIELD;
-  if (nv == 18 && nb <= 14) select_t<18, 14, 1>(e, hf);        // flamingo_light_v1
+  if (nv == 18 && nb <= 14) { select_t<18, 14, 1>(e, hf); if (!hf) e->launch_prof = launch_prof_t<18, 14, 1>; }   // flamingo_light_v1
   else if (nv == 14 && nb <= 10) select_t<14, 10, 2>(e, hf);   // flamingo_p_v3
   else if (nv == 22 && nb <= 18) select_t<22, 18, 2>(e, hf);   // w4_p_v2
   else if (nv == 29 && nb <= 26) select_t<29, 26, 2>(e, hf);   // humanoid_p_v0
@@ -375,6 +388,7 @@ int cosim_set_param(cosim_engine_t* e, const char* name, const float* host, int 
   else if (n == "meaninertia") { off = L.p_mean; width = 1; }
   else if (n == "solver_tolerance") { e->tol32 = host[0]; return COSIM_OK; }
   else if (n == "max_newton") { e->max_newton = (int)host[0]; return COSIM_OK; }
+  else if (n == "max_ls") { e->max_ls = (int)host[0]; return COSIM_OK; }
   else return fail(COSIM_EINVAL, "cosim_set_param: unknown parameter " + n);
   if (count != e->n_envs * width) return fail(COSIM_EINVAL, "cosim_set_param: " + n + " expects n_envs*" + std::to_string(width) + " values");
   for (int i = 0; i < e->n_envs; i++)
@@ -401,7 +415,7 @@ static KArgs base_args(cosim_engine* e) {
   a.dm = e->d_model; a.ob = e->d_obs; a.lay = e->lay; a.state = e->d_state; a.params = e->d_params;
   a.hull_vert = e->d_hull_vert; a.hull_adr = e->d_hull_adr; a.hull_nbr = e->d_hull_nbr; a.hfield = e->d_hfield;
   a.n_envs = e->n_envs; a.seed_lo = (unsigned)e->seed; a.seed_hi = (unsigned)(e->seed >> 32); a.env_id0 = e->env_id0;
-  a.tol32 = e->tol32; a.max_newton = e->max_newton;
+  a.tol32 = e->tol32; a.max_newton = e->max_newton; a.max_ls = e->max_ls;
   return a;
 }
 
@@ -512,6 +526,26 @@ int cosim_debug_forward(cosim_engine_t* e, int env, const char* name, float* hos
   HIP_TRY(hipDeviceSynchronize());
   int n = capacity < 8192 ? capacity : 8192;
   HIP_TRY(hipMemcpy(host_out, e->d_dbg, (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
+  return COSIM_OK;
+}
+
+int cosim_profile_step(cosim_engine_t* e, const float* actions_dev, const float* commands_dev, float* state_out_dev, uint8_t* terminated_dev,
+                       uint8_t* truncated_dev, double* cycles_out16) {
+  if (!e || !actions_dev || !state_out_dev || !terminated_dev || !truncated_dev || !cycles_out16) return fail(COSIM_EINVAL, "cosim_profile_step: null argument");
+  if (!e->launch_prof) return fail(COSIM_EINVAL, "cosim_profile_step: no diagnostic kernel for this model");
+  HIP_TRY(hipSetDevice(e->device));
+  int rc = upload_params(e);
+  if (rc) return rc;
+  HIP_TRY(hipMemset(e->d_dbg, 0, 8192 * sizeof(float)));
+  KArgs a = base_args(e);
+  a.mode = MODE_STEP; a.actions = actions_dev; a.commands = commands_dev; a.state_out = state_out_dev;
+  a.terminated = terminated_dev; a.truncated = truncated_dev; a.dbg = e->d_dbg;
+  e->launch_prof(e, a, e->n_envs, 0);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipDeviceSynchronize());
+  unsigned long long raw[16];
+  HIP_TRY(hipMemcpy(raw, e->d_dbg, sizeof raw, hipMemcpyDeviceToHost));
+  for (int i = 0; i < 16; i++) cycles_out16[i] = (double)raw[i] / (double)e->n_envs;
   return COSIM_OK;
 }
 

@@ -56,7 +56,7 @@ struct KArgs {
   unsigned seed_lo, seed_hi;
   long long env_id0;
   float tol32;            // fp32 solver tolerance
-  int max_newton;
+  int max_newton, max_ls;
 };
 
 // ------------------------------------------------------------------------------------------------ wave helpers
@@ -367,7 +367,7 @@ __device__ __forceinline__ float impedance(const float* solimp, float pos, float
 }
 
 // ------------------------------------------------------------------------------------------------ the kernel
-template <int NV, int NB, int RPL, bool HF>   // HF: heightfield ground (false: plane); kept out of the flat kernels' register budget
+template <int NV, int NB, int RPL, bool HF, bool PROF = false>   // HF: heightfield ground; PROF: diagnostic build with s_memtime phase stamps
 __global__ __launch_bounds__(64, RPL == 1 ? 4 : 2) void env_kernel(KArgs A) {
   using L = EnvLds<NV, NB, RPL>;
   constexpr int MAXROWS = L::ROWS;
@@ -386,6 +386,10 @@ __global__ __launch_bounds__(64, RPL == 1 ? 4 : 2) void env_kernel(KArgs A) {
   const float* par = A.params + (size_t)env * lay.p_stride;
   const int nbody = dm.nbody, nu = dm.nu, nq = dm.nq, ngeom = dm.ngeom;
   const float h = dm.timestep;
+  // diagnostic build only: shader-clock time per phase, summed over the substeps (never executed in the product kernel)
+  unsigned long long pt0 = 0, pacc[16];
+  if (PROF) { for (int i = 0; i < 16; i++) pacc[i] = 0; pt0 = __builtin_amdgcn_s_memtime(); }
+#define STAMP(i) do { if (PROF) { __builtin_amdgcn_s_waitcnt(0); unsigned long long t_ = __builtin_amdgcn_s_memtime(); pacc[i] += t_ - pt0; pt0 = t_; } } while (0)
 
   // ---- per-env parameters -> LDS
   if (lane < nbody) { S.p_mass[lane] = par[lay.p_mass + lane]; S.p_binvw[lane] = par[lay.p_binvw + lane]; }
@@ -471,6 +475,7 @@ __global__ __launch_bounds__(64, RPL == 1 ? 4 : 2) void env_kernel(KArgs A) {
     for (int sub = 0; sub < nsub; sub++) {
       int ln = lane;
       LAUNDER(ln);
+      STAMP(0);   // prologue / previous epilogue
       // =========================================================== mj_kinematics: level-synchronous over the tree
       {
         const LaneRec& R = dm.rec[ln];
@@ -520,6 +525,7 @@ __global__ __launch_bounds__(64, RPL == 1 ? 4 : 2) void env_kernel(KArgs A) {
         }
       }
 
+      STAMP(1);   // kinematics
       // =========================================================== mj_comPos: com, cinert (lane = body)
       float cinert[10];
 #pragma unroll
@@ -603,6 +609,7 @@ __global__ __launch_bounds__(64, RPL == 1 ? 4 : 2) void env_kernel(KArgs A) {
       }
       WSYNC();
 
+      STAMP(2);   // comPos + cdof
       // =========================================================== mj_crb: composite inertia of the dof's body, M row + column
       if (ln < NV) {
         const LaneRec& R = dm.rec[ln];
@@ -627,6 +634,7 @@ __global__ __launch_bounds__(64, RPL == 1 ? 4 : 2) void env_kernel(KArgs A) {
         }
       }
 
+      STAMP(3);   // crb
       // =========================================================== mj_comVel + mj_rne (bias) + passive + smooth force
       if (ln < NV) {
         const LaneRec& R = dm.rec[ln];
@@ -728,6 +736,7 @@ __global__ __launch_bounds__(64, RPL == 1 ? 4 : 2) void env_kernel(KArgs A) {
         }
       }
 
+      STAMP(4);   // comVel + rne + sensors
       // =========================================================== collision: ground (plane or heightfield) vs robot geoms
       int ncon = 0;
       {
@@ -755,7 +764,13 @@ __global__ __launch_bounds__(64, RPL == 1 ? 4 : 2) void env_kernel(KArgs A) {
         const float margin = R.g_margin, rb = R.g_rbound;
         if (is_plane) {
           const float nz[3] = {0.f, 0.f, 1.f};
-          if (active && gt == CS_GEOM_MESH) mesh_near = (ctr[2] - T.gz - rb) <= margin;
+          if (active && gt == CS_GEOM_MESH) {
+            // exact reject: lowest corner of the hull's body-frame box (oriented into the world) above the plane
+            float m[9];
+            q2m(m, xq);
+            const float low = ctr[2] - T.gz - (fabsf(m[6]) * R.g_half[0] + fabsf(m[7]) * R.g_half[1] + fabsf(m[8]) * R.g_half[2]);
+            mesh_near = low <= margin;
+          }
           else if (active) {
             cnt = prim_plane(R, xq, xp, gpos, nz, margin, acp, adst);
             for (int i = 0; i < cnt; i++) { anr[i][0] = 0.f; anr[i][1] = 0.f; anr[i][2] = 1.f; }
@@ -870,6 +885,7 @@ __global__ __launch_bounds__(64, RPL == 1 ? 4 : 2) void env_kernel(KArgs A) {
         }
       }
 
+      STAMP(5);   // collision
       // =========================================================== constraint rows (lane = row)
       const int ne = 3 * dm.neq, nf = dm.nfric;
       int nl = 0;
@@ -1020,6 +1036,7 @@ __global__ __launch_bounds__(64, RPL == 1 ? 4 : 2) void env_kernel(KArgs A) {
       }
       WSYNC();
 
+      STAMP(6);   // constraint rows
       // =========================================================== Newton solver (mj_solNewton), warm-started from qacc
       float Jaref[RPL], Jv[RPL], Ma = 0.f;
       float dinv = 1.f;
@@ -1101,32 +1118,39 @@ __global__ __launch_bounds__(64, RPL == 1 ? 4 : 2) void env_kernel(KArgs A) {
         bool changed = false;
 #pragma unroll
         for (int rr = 0; rr < RPL; rr++) changed = changed || (dact_cur[rr] != dact_fac[rr]);
+        unsigned long long q0_ = 0;
+        if (PROF) { __builtin_amdgcn_s_waitcnt(0); q0_ = __builtin_amdgcn_s_memtime(); }
         if (__ballot(changed) != 0ull) {
 #pragma unroll
           for (int rr = 0; rr < RPL; rr++) dact_fac[rr] = dact_cur[rr];
           st_build++;
-          {  // entry-parallel over the lower triangle, mirrored into a full square
-            int ea[EPL], eb[EPL];
-            float hacc[EPL];
+          {  // H = M + (D J)^T J on the matrix pipe: v_mfma_f32_32x32x2_f32, two constraint rows per instruction
+             // (exact fp32 FMA chain; inactive rows carry D = 0).  Lane l feeds A[i = l & 31][k = l >> 5] = D_k J[k][i]
+             // and B[k][j = l & 31] = J[k][j]; C/D: col = l & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (l >> 5).
+            typedef float f32x16 __attribute__((ext_vector_type(16)));
+            static_assert(NV <= 32, "one 32x32 MFMA tile");
+            const int col = ln & 31, half = ln >> 5;
+            f32x16 acc;
 #pragma unroll
-            for (int t = 0; t < EPL; t++) {
-              const int e = ln + 64 * t;
-              ea[t] = e < TRI ? dm.tri_row[e] : 0;
-              eb[t] = e < TRI ? dm.tri_col[e] : 0;
-              hacc[t] = S.M[ea[t]][eb[t]];
+            for (int v = 0; v < 16; v++) {
+              const int row = (v & 3) + 8 * (v >> 2) + 4 * half;
+              acc[v] = (row < NV && col < NV) ? S.M[row < NV ? row : 0][col < NV ? col : 0] : 0.f;
             }
-            for (int r = 0; r < ngen; r++) {
-              const float dr = rfl(S.w.r.rowD[r]);
-              if (dr == 0.f) continue;
-              const float* Jr = S.J[r];
-#pragma unroll
-              for (int t = 0; t < EPL; t++) hacc[t] += dr * Jr[ea[t]] * Jr[eb[t]];
+            for (int r0 = 0; r0 < ngen; r0 += 2) {
+              const int r = r0 + half;
+              const bool ok = r < ngen && col < NV;
+              const float jv = ok ? S.J[ok ? r : 0][ok ? col : 0] : 0.f;
+              const float dv = ok ? S.w.r.rowD[ok ? r : 0] : 0.f;
+              acc = __builtin_amdgcn_mfma_f32_32x32x2f32(jv * dv, jv, acc, 0, 0, 0);
             }
 #pragma unroll
-            for (int t = 0; t < EPL; t++)
-              if (ln + 64 * t < TRI) { S.u.H[ea[t]][eb[t]] = hacc[t]; S.u.H[eb[t]][ea[t]] = hacc[t]; }
+            for (int v = 0; v < 16; v++) {
+              const int row = (v & 3) + 8 * (v >> 2) + 4 * half;
+              if (row < NV && col < NV) S.u.H[row][col] = acc[v];
+            }
           }
           WSYNC();
+          if (PROF) { __builtin_amdgcn_s_waitcnt(0); unsigned long long t_ = __builtin_amdgcn_s_memtime(); pacc[10] += t_ - q0_; q0_ = t_; }   // Hessian build
           float a_row[NV];
           {
             const float* Hr = S.u.H[ln < NV ? ln : 0];
@@ -1142,9 +1166,11 @@ __global__ __launch_bounds__(64, RPL == 1 ? 4 : 2) void env_kernel(KArgs A) {
           }
           WSYNC();
         }
+        if (PROF) { __builtin_amdgcn_s_waitcnt(0); unsigned long long t_ = __builtin_amdgcn_s_memtime(); pacc[11] += t_ - q0_; q0_ = t_; }   // Cholesky + park
         const float mg = chol_solve_lds<NV, L::LD>(S.u.H, dinv, grad_l, ln);
         if (ln < NV) S.sr[ln] = -mg;
         WSYNC();
+        if (PROF) { __builtin_amdgcn_s_waitcnt(0); unsigned long long t_ = __builtin_amdgcn_s_memtime(); pacc[12] += t_ - q0_; }   // triangular solves
       };
 
       update_constraint();
@@ -1164,6 +1190,8 @@ __global__ __launch_bounds__(64, RPL == 1 ? 4 : 2) void env_kernel(KArgs A) {
       while (niter < maxiter) {
         if (scale * gradnorm < A.tol32) break;
         update_search();
+        unsigned long long q1_ = 0;
+        if (PROF) { __builtin_amdgcn_s_waitcnt(0); q1_ = __builtin_amdgcn_s_memtime(); }
         // ---- exact line search on the piecewise-quadratic cost (PrimalSearch)
         const float sr_l = ln < NV ? S.sr[ln] : 0.f;
         const float Mv = mulM(S.sr);
@@ -1206,8 +1234,15 @@ __global__ __launch_bounds__(64, RPL == 1 ? 4 : 2) void env_kernel(KArgs A) {
         int lsit_total = 0;
         {
           int lsit = 0;
-          const int maxls = min(dm.ls_iterations, 24);
-          Pnt p0 = eval(0.f); lsit++;
+          const int maxls = min(dm.ls_iterations, A.max_ls);
+          // PrimalSearch starts with an evaluation at alpha = 0; for the Newton direction its value and derivatives are
+          // known in closed form: phi(0) = cost, phi'(0) = g.s, phi''(0) = s'Hs = -g.s (H s = -g on the current active set)
+          Pnt p0;
+          {
+            const float gs = wave_sum(grad_l * sr_l);
+            p0.alpha = 0.f; p0.cost = cost; p0.d0 = gs; p0.d1 = -gs;
+            if (!(p0.d1 > 0.f)) p0.d1 = 1e-15f;
+          }
           Pnt p1 = eval(p0.alpha - p0.d0 / p0.d1); lsit++;
           if (p0.cost < p1.cost) p1 = p0;
           bool done = false;
@@ -1262,6 +1297,7 @@ __global__ __launch_bounds__(64, RPL == 1 ? 4 : 2) void env_kernel(KArgs A) {
           lsit_total = lsit;
         }
         alpha = rfl(alpha);
+        if (PROF) { __builtin_amdgcn_s_waitcnt(0); unsigned long long t_ = __builtin_amdgcn_s_memtime(); pacc[13] += t_ - q1_; q1_ = t_; }   // line search
         st_ls += lsit_total;
         if (alpha == 0.f) break;
         // ---- move
@@ -1274,6 +1310,7 @@ __global__ __launch_bounds__(64, RPL == 1 ? 4 : 2) void env_kernel(KArgs A) {
         update_constraint();
         gradnorm = sqrtf(wave_sum(grad_l * grad_l));
         niter++;
+        if (PROF) { __builtin_amdgcn_s_waitcnt(0); unsigned long long t_ = __builtin_amdgcn_s_memtime(); pacc[14] += t_ - q1_; }   // move + constraint update
         const float improvement = scale * (oldcost - cost);
         if (improvement < A.tol32) break;
       }
@@ -1288,6 +1325,7 @@ __global__ __launch_bounds__(64, RPL == 1 ? 4 : 2) void env_kernel(KArgs A) {
         if (ln < 3) { D[20 + ln] = s_gyro[ln]; D[24 + ln] = s_vel[ln]; }
       }
 
+      STAMP(7);   // Newton (sub-phases 10..14 inside)
       // =========================================================== _is_done of flamingo_p_v3 (flamingo_p_v3.py:225-233)
       // cfrc_ext of mj_rnePostConstraint for the listed bodies: sum of contact wrenches [torque; force], world aligned,
       // about the tree's CoM; "any signed component > 1.0" terminates.  Uses the last substep's contacts and forces.
@@ -1361,6 +1399,7 @@ __global__ __launch_bounds__(64, RPL == 1 ? 4 : 2) void env_kernel(KArgs A) {
           if (ln < NV) A.dbg[1080 + ln] = qa;
         }
       }
+      STAMP(8);   // implicitfast + advance
     }  // substeps
     if (A.mode == MODE_DEBUG) return;
 
@@ -1446,7 +1485,7 @@ __global__ __launch_bounds__(64, RPL == 1 ? 4 : 2) void env_kernel(KArgs A) {
       if (ob.noise_enabled && f != CS_OBS_LAST_ACTION && f != CS_OBS_COMMAND) {
         // truncated Gaussian by inverse CDF (scipy.stats.truncnorm.rvs, noise_generator_utils.py:22-28)
         const float mean = ob.noise_mean[f], sd_ = ob.noise_std[f];
-        const float ca = normcdff((ob.noise_lower[f] - mean) / sd_), cb = normcdff((ob.noise_upper[f] - mean) / sd_);
+        const float ca = ob.noise_ca[f], cb = ob.noise_cb[f];
         float z = normcdfinvf(ca + u01(philox_first(k0, k1, step_count, 1u, (unsigned)e, 0u)) * (cb - ca));
         float nz = fminf(ob.noise_upper[f], fmaxf(ob.noise_lower[f], mean + sd_ * z));
         val += nz;
@@ -1489,6 +1528,9 @@ __global__ __launch_bounds__(64, RPL == 1 ? 4 : 2) void env_kernel(KArgs A) {
     }
     if (lane == 0) { A.terminated[env] = (uint8_t)terminated; A.truncated[env] = (uint8_t)truncated; }
   }
+  STAMP(9);   // observation build + info
+  if (PROF && A.dbg != nullptr && lane == 0)
+    for (int i = 0; i < 16; i++) atomicAdd(reinterpret_cast<unsigned long long*>(A.dbg) + i, pacc[i]);
   if (lane < nq) rec[lay.s_qpos + lane] = S.qpos[lane];
   if (lane < NV) { rec[lay.s_qvel + lane] = S.qvel[lane]; rec[lay.s_warm + lane] = S.qacc[lane]; }
   if (lane < nu) rec[lay.s_lastact + lane] = do_reset ? 0.f : raw_action;

@@ -87,10 +87,11 @@ def load_library():
     L.cosim_debug_forward.argtypes = [vp, ci, ctypes.c_char_p, vp, ci]
     L.cosim_kernel_time.argtypes = [vp, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ci)]
     L.cosim_set_timing.argtypes = [vp, ci]
+    L.cosim_profile_step.argtypes = [vp] * 7
     L.cosim_last_error.restype = ctypes.c_char_p
     for fn in ("cosim_create", "cosim_destroy", "cosim_query", "cosim_set_param", "cosim_reset", "cosim_step", "cosim_get",
                "cosim_set", "cosim_event_push", "cosim_debug_forward", "cosim_kernel_time", "cosim_set_timing",
-               "cosim_model_sizeof", "cosim_obs_config_sizeof"):
+               "cosim_profile_step", "cosim_model_sizeof", "cosim_obs_config_sizeof"):
         getattr(L, fn).restype = ci
     if L.cosim_model_sizeof() != ctypes.sizeof(CosimModel):
         raise RuntimeError("cosim_model_t layout mismatch between include/cosim_model.h and libcosim_hip.so: rebuild")
@@ -102,7 +103,7 @@ def load_library():
 
 EXPORTS = ["cosim_create", "cosim_destroy", "cosim_query", "cosim_set_param", "cosim_reset", "cosim_step", "cosim_get",
            "cosim_set", "cosim_event_push", "cosim_debug_forward", "cosim_kernel_time", "cosim_set_timing",
-           "cosim_last_error", "cosim_model_sizeof", "cosim_obs_config_sizeof"]
+           "cosim_profile_step", "cosim_last_error", "cosim_model_sizeof", "cosim_obs_config_sizeof"]
 
 
 def make_obs_config(config: dict, obs_to_dim: Dict[str, int], control_freq: float, auto_reset: bool) -> ObsConfig:
@@ -228,6 +229,11 @@ class Engine:
     def debug_forward(self, env: int) -> np.ndarray:
         out = np.zeros(8192, dtype=np.float32)
         self._check(self.L.cosim_debug_forward(self.h, int(env), b"all", out.ctypes.data, out.size))
+        return out
+
+    def profile_step(self, actions_ptr, commands_ptr, state_out_ptr, term_ptr, trunc_ptr) -> np.ndarray:
+        out = np.zeros(16, dtype=np.float64)
+        self._check(self.L.cosim_profile_step(self.h, actions_ptr, commands_ptr, state_out_ptr, term_ptr, trunc_ptr, out.ctypes.data))
         return out
 
     def set_timing(self, enabled: bool):

@@ -96,6 +96,7 @@ typedef struct cosim_model {
   double geom_solmix[CS_MAXGEOM], geom_margin[CS_MAXGEOM], geom_gap[CS_MAXGEOM];
   double geom_rbound[CS_MAXGEOM];     /* bounding-sphere radius about geom_rcenter (body frame) */
   double geom_rcenter[CS_MAXGEOM][3];
+  double geom_aabb[CS_MAXGEOM][6];    /* body-frame box around the geom: centre xyz, half-extent xyz (broadphase) */
   int pair_geom1[CS_MAXPAIR], pair_geom2[CS_MAXPAIR]; /* robot-robot candidate pairs (self collision) */
 
   /* equality: connect */
