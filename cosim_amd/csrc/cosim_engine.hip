@@ -53,18 +53,18 @@ struct cosim_engine {
   int lds_bytes = 0;
 };
 
-template <int NV, int NB, int RPL, bool HF>
+template <int NV, int NB, int RPL, bool HF, int GTM>
 static void launch_t(cosim_engine* e, const KArgs& a, int grid, hipStream_t s) {
-  hipLaunchKernelGGL((env_kernel<NV, NB, RPL, HF>), dim3(grid), dim3(64), 0, s, a);
+  hipLaunchKernelGGL((env_kernel<NV, NB, RPL, HF, GTM>), dim3(grid), dim3(64), 0, s, a);
 }
-template <int NV, int NB, int RPL>
+template <int NV, int NB, int RPL, int GTM>
 static void launch_prof_t(cosim_engine* e, const KArgs& a, int grid, hipStream_t s) {
-  hipLaunchKernelGGL((env_kernel<NV, NB, RPL, false, true>), dim3(grid), dim3(64), 0, s, a);
+  hipLaunchKernelGGL((env_kernel<NV, NB, RPL, false, GTM, true>), dim3(grid), dim3(64), 0, s, a);
 }
-template <int NV, int NB, int RPL>
+template <int NV, int NB, int RPL, int GTM>
 static void select_t(cosim_engine* e, bool hf) {
-  e->launch = hf ? launch_t<NV, NB, RPL, true> : launch_t<NV, NB, RPL, false>;
-  e->lds_bytes = (int)sizeof(EnvLds<NV, NB, RPL>);
+  e->launch = hf ? launch_t<NV, NB, RPL, true, GTM> : launch_t<NV, NB, RPL, false, GTM>;
+  e->lds_bytes = hf ? (int)sizeof(EnvLds<NV, NB, RPL, true>) : (int)sizeof(EnvLds<NV, NB, RPL, false>);
 }
 
 static int round_up(int x, int m) { return (x + m - 1) / m * m; }
@@ -308,10 +308,22 @@ int cosim_create(const cosim_model_t* model, const float* hull_vert, const int* 
   const int nv = model->nv, nb = model->nbody;
   // kernel instantiations: (nv, nbody) of the four cosim robots; RPL = constraint rows per lane
   const bool hf = model->ground_type == CS_GEOM_HFIELD;
-  if (nv == 18 && nb <= 14) { select_t<18, 14, 1>(e, hf); if (!hf) e->launch_prof = launch_prof_t<18, 14, 1>; }   // flamingo_light_v1
-  else if (nv == 14 && nb <= 10) select_t<14, 10, 2>(e, hf);   // flamingo_p_v3
-  else if (nv == 22 && nb <= 18) select_t<22, 18, 2>(e, hf);   // w4_p_v2
-  else if (nv == 29 && nb <= 26) select_t<29, 26, 2>(e, hf);   // humanoid_p_v0
+  int gtm = 0;   // geom types present: the kernel is specialised on them (bit 0 sphere, 1 cylinder, 2 box, 3 mesh)
+  for (int g = 0; g < model->ngeom; g++) {
+    if (!model->geom_ground[g]) continue;
+    switch (model->geom_type[g]) {
+      case CS_GEOM_SPHERE: gtm |= GT_SPHERE; break;
+      case CS_GEOM_CYLINDER: gtm |= GT_CYLINDER; break;
+      case CS_GEOM_BOX: gtm |= GT_BOX; break;
+      case CS_GEOM_MESH: gtm |= GT_MESH; break;
+      default: delete e; return fail(COSIM_EINVAL, "cosim_create: collision geom type not implemented in the HIP engine");
+    }
+  }
+  constexpr int G_LIGHT = GT_SPHERE | GT_CYLINDER | GT_MESH, G_MESH = GT_MESH, G_HUM = GT_BOX | GT_CYLINDER | GT_MESH;
+  if (nv == 18 && nb <= 14 && (gtm & ~G_LIGHT) == 0) { select_t<18, 14, 1, G_LIGHT>(e, hf); if (!hf) e->launch_prof = launch_prof_t<18, 14, 1, G_LIGHT>; }   // flamingo_light_v1
+  else if (nv == 14 && nb <= 10 && (gtm & ~G_MESH) == 0) select_t<14, 10, 2, G_MESH>(e, hf);   // flamingo_p_v3
+  else if (nv == 22 && nb <= 18 && (gtm & ~G_MESH) == 0) select_t<22, 18, 2, G_MESH>(e, hf);   // w4_p_v2
+  else if (nv == 29 && nb <= 26 && (gtm & ~G_HUM) == 0) select_t<29, 26, 2, G_HUM>(e, hf);     // humanoid_p_v0
   else { delete e; return fail(COSIM_EINVAL, "cosim_create: no kernel instantiation for this (nv, nbody); add one in cosim_engine.hip"); }
   HIP_TRY(hipMalloc(&e->d_model, sizeof(DevModel)));
   HIP_TRY(hipMalloc(&e->d_obs, sizeof(DevObs)));

@@ -157,7 +157,7 @@ __device__ __forceinline__ unsigned philox_first(unsigned k0, unsigned k1, unsig
 __device__ __forceinline__ float u01(unsigned x) { return (float)(x >> 8) * (1.0f / 16777216.0f) + (0.5f / 16777216.0f); }  // (0,1)
 
 // ------------------------------------------------------------------------------------------------ LDS per env
-template <int NV, int NB, int RPL>
+template <int NV, int NB, int RPL, bool HF>
 struct EnvLds {
   static constexpr int LD = NV | 1;   // odd leading dimension: conflict-free column access
   static constexpr int ROWS = 64 * RPL;            // constraint rows per env: RPL rows per lane
@@ -177,13 +177,15 @@ struct EnvLds {
     struct { float rowf[ROWS], rowD[ROWS]; } r;
   } w;
   float J[NGEN][LD];
-  float cpos[MC][3], cnrm[MC][3], cdist[MC];
+  float cpos[MC][3], cnrm[HF ? MC : 1][3], cdist[MC];   // contact normals are +z on the plane: not stored
   int cgeom[MC];
   int lim_body[NLIM];
   float lim_sign[NLIM], lim_dist[NLIM];
   float p_mass[NB], p_binvw[NB], p_dinvw[NV], p_floss[NV], p_gmu[32];
-  float act[MAXU], cmd[CS_MAXCMD + 2];
-  float com[4];
+  float act[MAXU], tq[MAXU], cmd[CS_MAXCMD + 2];
+  float sens[10];   // framequat[4], gyro[3], velocimeter[3] of the last substep's forward pass
+  float com[3];
+  int ncon_ctr;
 };
 
 // ------------------------------------------------------------------------------------------------ Cholesky
@@ -225,24 +227,35 @@ __device__ __forceinline__ float chol_solve_lds(const float (*Lm)[LD], float din
 
 // ------------------------------------------------------------------------------------------------ geometry helpers
 // Contacts of one primitive geom (sphere / cylinder / box) against the plane through P0 with unit normal n:
-// mjc_PlaneSphere / mjc_PlaneCylinder / mjc_PlaneBox (engine_collision_primitive.c).  Returns the contact count (<= 4).
-__device__ __forceinline__ int prim_plane(const LaneRec& R, const float* xq, const float* xp, const float* P0, const float* n,
-                                          float margin, float (*cp)[3], float* cdst) {
-  int cnt = 0;
-  float v[3], pos[3], gq[4], mat[9];
+// mjc_PlaneSphere / mjc_PlaneCylinder / mjc_PlaneBox (engine_collision_primitive.c), split in two steps so that nothing is
+// ever indexed dynamically (a dynamically indexed local array lives in scratch memory) and little is live at once:
+//   prim_plane_mask  -> which of the (at most four) candidate points touch, plus the few vectors they are built from;
+//   prim_plane_point -> candidate j (compile-time j) as {dist, position}.
+// The j-th contact of the geom is the j-th set bit of the mask, in MuJoCo's order.
+// GTM: geom types present in the model (bit 0 sphere, 1 cylinder, 2 box, 3 mesh): absent types cost no registers.
+constexpr int GT_SPHERE = 1, GT_CYLINDER = 2, GT_BOX = 4, GT_MESH = 8;
+struct PrimCtx {
+  float pos[3], a[3], b[3], c[3];  // geom centre; cylinder: half axis, rim vector, 120-degree rim vector; box: mat rows via a, b, c
+  float dist0, d[4];
+  unsigned mask;                   // cylinder / sphere: candidate bits; box: low 8 bits = touching corners
+  int gt;
+};
+template <int GTM>
+__device__ __forceinline__ void prim_plane_mask(const LaneRec& R, const float* xq, const float* xp, const float* P0, const float* n,
+                                                float margin, PrimCtx& cx) {
+  cx.mask = 0u;
+  cx.gt = R.g_type;
+  float v[3], gq[4], mat[9];
   qrot(v, xq, R.g_pos);
-  for (int k = 0; k < 3; k++) pos[k] = xp[k] + v[k];
-  const float dist0 = n[0] * (pos[0] - P0[0]) + n[1] * (pos[1] - P0[1]) + n[2] * (pos[2] - P0[2]);
-  const int gt = R.g_type;
-  if (gt == CS_GEOM_SPHERE) {
+  for (int k = 0; k < 3; k++) { cx.pos[k] = xp[k] + v[k]; cx.a[k] = 0.f; cx.b[k] = 0.f; cx.c[k] = 0.f; }
+  for (int k = 0; k < 4; k++) cx.d[k] = 0.f;
+  const float dist0 = n[0] * (cx.pos[0] - P0[0]) + n[1] * (cx.pos[1] - P0[1]) + n[2] * (cx.pos[2] - P0[2]);
+  cx.dist0 = dist0;
+  if ((GTM & GT_SPHERE) && cx.gt == CS_GEOM_SPHERE) {
     const float r = R.g_size[0];
-    if (dist0 <= margin + r) {
-      const float dist = dist0 - r;
-      cdst[0] = dist;
-      for (int k = 0; k < 3; k++) cp[0][k] = pos[k] - n[k] * (r + 0.5f * dist);
-      cnt = 1;
-    }
-  } else if (gt == CS_GEOM_CYLINDER) {
+    cx.d[0] = dist0 - r;
+    cx.mask = dist0 <= margin + r ? 1u : 0u;
+  } else if ((GTM & GT_CYLINDER) && cx.gt == CS_GEOM_CYLINDER) {
     qmul(gq, xq, R.g_quat);
     q2m(mat, gq);
     const float radius = R.g_size[0], half = R.g_size[1];
@@ -256,50 +269,57 @@ __device__ __forceinline__ int prim_plane(const LaneRec& R, const float* xq, con
     const float prjvec = dot3(vec, n);
     axis[0] *= half; axis[1] *= half; axis[2] *= half;
     prjaxis *= half;
-    float dist = dist0 + prjaxis + prjvec;
-    if (dist <= margin) {
-      cdst[0] = dist;
-      for (int k = 0; k < 3; k++) cp[0][k] = pos[k] + vec[k] + axis[k] - n[k] * dist * 0.5f;
-      cnt = 1;
-      dist = dist0 - prjaxis + prjvec;
-      if (dist <= margin) {
-        cdst[cnt] = dist;
-        for (int k = 0; k < 3; k++) cp[cnt][k] = pos[k] + vec[k] - axis[k] - n[k] * dist * 0.5f;
-        cnt++;
-      }
-      float vec1[3];
-      cross(vec1, vec, axis);
-      const float s1 = radius * 0.8660254037844386f * rsqrtf(fmaxf(dot3(vec1, vec1), 1e-30f));
-      vec1[0] *= s1; vec1[1] *= s1; vec1[2] *= s1;
-      const float prjvec1 = dot3(vec1, n);
-      dist = dist0 + prjaxis - prjvec * 0.5f + prjvec1;
-      if (dist <= margin) {
-        cdst[cnt] = dist;
-        for (int k = 0; k < 3; k++) cp[cnt][k] = pos[k] + vec1[k] + axis[k] - vec[k] * 0.5f - n[k] * dist * 0.5f;
-        cnt++;
-      }
-      dist = dist0 + prjaxis - prjvec * 0.5f - prjvec1;
-      if (dist <= margin) {
-        cdst[cnt] = dist;
-        for (int k = 0; k < 3; k++) cp[cnt][k] = pos[k] - vec1[k] + axis[k] - vec[k] * 0.5f - n[k] * dist * 0.5f;
-        cnt++;
-      }
-    }
-  } else if (gt == CS_GEOM_BOX) {
+    float vec1[3];
+    cross(vec1, vec, axis);
+    const float s1 = radius * 0.8660254037844386f * rsqrtf(fmaxf(dot3(vec1, vec1), 1e-30f));
+    vec1[0] *= s1; vec1[1] *= s1; vec1[2] *= s1;
+    const float prjvec1 = dot3(vec1, n);
+    // candidate 0: deepest rim point of the near disk; 1: same rim point of the far disk; 2, 3: +-120 degrees on the near disk
+    cx.d[0] = dist0 + prjaxis + prjvec;
+    cx.d[1] = dist0 - prjaxis + prjvec;
+    cx.d[2] = dist0 + prjaxis - prjvec * 0.5f + prjvec1;
+    cx.d[3] = dist0 + prjaxis - prjvec * 0.5f - prjvec1;
+    for (int k = 0; k < 3; k++) { cx.a[k] = axis[k]; cx.b[k] = vec[k]; cx.c[k] = vec1[k]; }
+    const bool first = cx.d[0] <= margin;  // nothing can touch unless the deepest point does
+    cx.mask = first ? (1u | (cx.d[1] <= margin ? 2u : 0u) | (cx.d[2] <= margin ? 4u : 0u) | (cx.d[3] <= margin ? 8u : 0u)) : 0u;
+  } else if ((GTM & GT_BOX) && cx.gt == CS_GEOM_BOX) {
     qmul(gq, xq, R.g_quat);
     q2m(mat, gq);
-    for (int i = 0; i < 8 && cnt < 4; i++) {
-      const float vx = (i & 1) ? R.g_size[0] : -R.g_size[0], vy = (i & 2) ? R.g_size[1] : -R.g_size[1], vz = (i & 4) ? R.g_size[2] : -R.g_size[2];
-      const float c[3] = {mat[0] * vx + mat[1] * vy + mat[2] * vz, mat[3] * vx + mat[4] * vy + mat[5] * vz, mat[6] * vx + mat[7] * vy + mat[8] * vz};
-      const float ld = dot3(n, c);
-      if (dist0 + ld > margin || ld > 0.f) continue;
-      const float dist = dist0 + ld;
-      cdst[cnt] = dist;
-      for (int k = 0; k < 3; k++) cp[cnt][k] = pos[k] + c[k] - n[k] * dist * 0.5f;
-      cnt++;
+    // corner i = sum_k (+-size_k) * column k of mat; keep n . column_k * size_k and the scaled columns
+    for (int k = 0; k < 3; k++) { cx.a[k] = mat[3 * k] * R.g_size[0]; cx.b[k] = mat[3 * k + 1] * R.g_size[1]; cx.c[k] = mat[3 * k + 2] * R.g_size[2]; }
+    const float na = dot3(n, cx.a), nb = dot3(n, cx.b), nc = dot3(n, cx.c);
+    unsigned m8 = 0u;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      const float ld = ((i & 1) ? na : -na) + ((i & 2) ? nb : -nb) + ((i & 4) ? nc : -nc);
+      if (!(dist0 + ld > margin || ld > 0.f)) m8 |= 1u << i;
     }
+    // at most the first four touching corners, in corner-index order (mjc_PlaneBox)
+    unsigned keep = 0u, rest = m8;
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+      if (rest) { keep |= rest & (0u - rest); rest &= rest - 1; }
+    cx.mask = keep;   // corner bits (0..255); contact j = j-th set bit
+    cx.d[0] = na; cx.d[1] = nb; cx.d[2] = nc;
   }
-  return cnt;
+}
+// number of contacts, and the candidate index of the j-th contact's bit (identity for sphere / cylinder)
+__device__ __forceinline__ int prim_count(const PrimCtx& cx) { return __popc(cx.mask); }
+// candidate `bit` (a set bit position of cx.mask) as {dist, pos}
+__device__ __forceinline__ void prim_plane_point(const PrimCtx& cx, const float* n, int bit, float& dist, float* p) {
+  if (cx.gt == CS_GEOM_SPHERE) {
+    dist = cx.d[0];
+    const float a = (cx.dist0 - dist) + 0.5f * dist;  // r + dist / 2
+    for (int k = 0; k < 3; k++) p[k] = cx.pos[k] - n[k] * a;
+  } else if (cx.gt == CS_GEOM_CYLINDER) {
+    dist = bit == 0 ? cx.d[0] : (bit == 1 ? cx.d[1] : (bit == 2 ? cx.d[2] : cx.d[3]));
+    const float sa = bit == 1 ? -1.f : 1.f, sb = bit < 2 ? 1.f : -0.5f, sc = bit == 2 ? 1.f : (bit == 3 ? -1.f : 0.f);
+    for (int k = 0; k < 3; k++) p[k] = cx.pos[k] + sa * cx.a[k] + sb * cx.b[k] + sc * cx.c[k] - n[k] * dist * 0.5f;
+  } else {  // box corner `bit`
+    const float s0 = (bit & 1) ? 1.f : -1.f, s1 = (bit & 2) ? 1.f : -1.f, s2 = (bit & 4) ? 1.f : -1.f;
+    dist = cx.dist0 + s0 * cx.d[0] + s1 * cx.d[1] + s2 * cx.d[2];
+    for (int k = 0; k < 3; k++) p[k] = cx.pos[k] + s0 * cx.a[k] + s1 * cx.b[k] + s2 * cx.c[k] - n[k] * dist * 0.5f;
+  }
 }
 
 struct Terrain {  // heightfield geometry; (ox, oy) = world position of the local frame origin (the base's x, y)
@@ -367,9 +387,9 @@ __device__ __forceinline__ float impedance(const float* solimp, float pos, float
 }
 
 // ------------------------------------------------------------------------------------------------ the kernel
-template <int NV, int NB, int RPL, bool HF, bool PROF = false>   // HF: heightfield ground; PROF: diagnostic build with s_memtime phase stamps
+template <int NV, int NB, int RPL, bool HF, int GTM, bool PROF = false>   // HF: heightfield ground; PROF: diagnostic build with s_memtime phase stamps
 __global__ __launch_bounds__(64, RPL == 1 ? 4 : 2) void env_kernel(KArgs A) {
-  using L = EnvLds<NV, NB, RPL>;
+  using L = EnvLds<NV, NB, RPL, HF>;
   constexpr int MAXROWS = L::ROWS;
   constexpr int TRI = NV * (NV + 1) / 2;
   constexpr int MC = L::MC;
@@ -428,10 +448,9 @@ __global__ __launch_bounds__(64, RPL == 1 ? 4 : 2) void env_kernel(KArgs A) {
   }
 
   // sensor values of the last forward pass (uniform across the wave)
-  float s_quat[4] = {1.f, 0.f, 0.f, 0.f}, s_gyro[3] = {0.f, 0.f, 0.f}, s_vel[3] = {0.f, 0.f, 0.f};
-  float raw_action = 0.f;   // lane u: self.action of this step
-  float prev_action = 0.f;  // lane u: self.prev_action (raw action of the previous step)
-  float tq_lane = 0.f;
+  // (sensor values of the last forward pass, the raw action and the applied torque live in LDS: S.sens, S.act, S.tq)
+  if (lane < MAXU) { S.act[lane] = 0.f; S.tq[lane] = 0.f; }
+  if (lane < 10) S.sens[lane] = lane == 0 ? 1.f : 0.f;
   int terminated = 0, truncated = 0, bad = 0;
   int st_newton = 0, st_ls = 0, st_build = 0, st_rows = 0;  // solver statistics of this control step
 
@@ -446,8 +465,8 @@ __global__ __launch_bounds__(64, RPL == 1 ? 4 : 2) void env_kernel(KArgs A) {
       const bool delayed = (ob.action_delay_prob > u01(philox_first(k0, k1, step_count, 0u, 0u, 0u))) && has_prev;  // control_manager.py:15-23
       if (lane < nu) {
         const LaneRec& R = dm.rec[lane];
-        raw_action = A.actions[(size_t)env * nu + lane];
-        prev_action = rec[lay.s_lastact + lane];
+        const float raw_action = A.actions[(size_t)env * nu + lane];
+        S.act[lane] = raw_action;
         float filt = delayed ? rec[lay.s_delay + lane] : raw_action;
         rec[lay.s_delay + lane] = raw_action;
         float a = filt * R.a_scale, g = R.a_cgear;
@@ -456,7 +475,7 @@ __global__ __launch_bounds__(64, RPL == 1 ? 4 : 2) void env_kernel(KArgs A) {
         float t = R.a_velmode ? kd * (a - qd) : kp * (a - q) + kd * (0.f - qd);
         t *= R.a_gamma;
         t = fminf(R.a_maxtq, fmaxf(-R.a_maxtq, t));
-        tq_lane = t;
+        S.tq[lane] = t;
         // mj_fwdActuation: ctrl clamp, gear, then the joint-level actuatorfrcrange clamp (one motor per dof)
         float c = R.a_ctrllimited ? fminf(R.a_ctrlrange[1], fmaxf(R.a_ctrlrange[0], t)) : t;
         float f = R.a_gear * c;
@@ -712,8 +731,10 @@ __global__ __launch_bounds__(64, RPL == 1 ? 4 : 2) void env_kernel(KArgs A) {
       if (sub == nsub - 1) {
         const int ib = dm.imu_body;
         float xq[4] = {S.xquat[ib][0], S.xquat[ib][1], S.xquat[ib][2], S.xquat[ib][3]};
+        float s_quat[4];
         qmul(s_quat, xq, dm.imu_quat);
         qnorm(s_quat);
+        if (ln < 4) S.sens[ln] = ln == 0 ? s_quat[0] : (ln == 1 ? s_quat[1] : (ln == 2 ? s_quat[2] : s_quat[3]));
         float cv[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         for (unsigned mk = dm.imu_dofmask; mk; mk &= mk - 1) {
           const int j = __builtin_ctz(mk);
@@ -732,7 +753,7 @@ __global__ __launch_bounds__(64, RPL == 1 ? 4 : 2) void env_kernel(KArgs A) {
           float l = m[k] * lin[0] + m[3 + k] * lin[1] + m[6 + k] * lin[2];
           if (dm.gyro_cutoff > 0.f) g = fminf(dm.gyro_cutoff, fmaxf(-dm.gyro_cutoff, g));
           if (dm.vel_cutoff > 0.f) l = fminf(dm.vel_cutoff, fmaxf(-dm.vel_cutoff, l));
-          s_gyro[k] = g; s_vel[k] = l;
+          if (ln == 0) { S.sens[4 + k] = g; S.sens[7 + k] = l; }
         }
       }
 
@@ -747,8 +768,6 @@ __global__ __launch_bounds__(64, RPL == 1 ? 4 : 2) void env_kernel(KArgs A) {
         T.sx = dm.hfield_size[0]; T.sy = dm.hfield_size[1]; T.sz = dm.hfield_size[2]; T.gz = dm.ground_pos[2];
         T.ox = (double)S.qpos[0] - (double)dm.ground_pos[0]; T.oy = (double)S.qpos[1] - (double)dm.ground_pos[1];
         T.dx = is_plane ? 1.0 : 2.0 * (double)T.sx / (double)(T.ncol - 1); T.dy = is_plane ? 1.0 : 2.0 * (double)T.sy / (double)(T.nrow - 1);
-        float acp[4][3], anr[4][3], adst[4];   // this lane's (geom's) contacts
-        int cnt = 0;
         bool mesh_near = false;
         const float gpos[3] = {0.f, 0.f, T.gz};
         const bool active = ln < ngeom && R.g_ground;
@@ -764,58 +783,87 @@ __global__ __launch_bounds__(64, RPL == 1 ? 4 : 2) void env_kernel(KArgs A) {
         const float margin = R.g_margin, rb = R.g_rbound;
         if (is_plane) {
           const float nz[3] = {0.f, 0.f, 1.f};
+          PrimCtx cx;
+          cx.mask = 0u;
           if (active && gt == CS_GEOM_MESH) {
             // exact reject: lowest corner of the hull's body-frame box (oriented into the world) above the plane
             float m[9];
             q2m(m, xq);
             const float low = ctr[2] - T.gz - (fabsf(m[6]) * R.g_half[0] + fabsf(m[7]) * R.g_half[1] + fabsf(m[8]) * R.g_half[2]);
             mesh_near = low <= margin;
+          } else if (active) prim_plane_mask<GTM>(R, xq, xp, gpos, nz, margin, cx);
+          // compaction in (geom, contact) order: slot = contacts of lower lanes + rank inside this geom
+          const int cnt = prim_count(cx);
+          int off = 0, total = 0;
+#pragma unroll
+          for (int s2 = 0; s2 < 4; s2++) {
+            unsigned long long mk = __ballot(cnt > s2);
+            off += __popcll(mk & lanemask_lt(ln));
+            total += __popcll(mk);
           }
-          else if (active) {
-            cnt = prim_plane(R, xq, xp, gpos, nz, margin, acp, adst);
-            for (int i = 0; i < cnt; i++) { anr[i][0] = 0.f; anr[i][1] = 0.f; anr[i][2] = 1.f; }
+          {
+            unsigned rest = cx.mask;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+              if (rest) {
+                const int bit = __builtin_ctz(rest);
+                rest &= rest - 1;
+                const int slot = off + j;
+                if (slot < MC) {
+                  float dist, pnt[3];
+                  prim_plane_point(cx, nz, bit, dist, pnt);
+                  S.cdist[slot] = dist;
+                  S.cgeom[slot] = ln;
+                  S.cpos[slot][0] = pnt[0]; S.cpos[slot][1] = pnt[1]; S.cpos[slot][2] = pnt[2];
+                }
+              }
+            }
           }
-        } else if (active) {
+          ncon = total;
+        } else {
+          // heightfield: contacts are appended through an LDS counter (order: loop iteration, then lane)
+          if (ln == 0) S.ncon_ctr = 0;
+          WSYNC();
           int rmin, rmax, cmin, cmax;
-          if (terrain_cells(T, ctr, rb, rmin, rmax, cmin, cmax)) {
+          if (active && terrain_cells(T, ctr, rb, rmin, rmax, cmin, cmax)) {
             if (gt == CS_GEOM_MESH) mesh_near = true;   // refined per triangle below
             else {
+              int gcnt = 0;
               for (int r = rmin; r <= rmax; r++)
                 for (int c = cmin; c <= cmax; c++)
                   for (int t = 0; t < 2; t++) {
-                    if (cnt >= 4) continue;
+                    if (gcnt >= 4) continue;
                     float P0[3], n[3];
                     terrain_triangle(T, r, c, t, P0, n);
                     if (n[0] * (ctr[0] - P0[0]) + n[1] * (ctr[1] - P0[1]) + n[2] * (ctr[2] - P0[2]) - rb > margin) continue;
-                    float cp[4][3], cdst[4];
-                    const int k4 = prim_plane(R, xq, xp, P0, n, margin, cp, cdst);
-                    for (int i = 0; i < k4; i++)
-                      if (cnt < 4 && terrain_footprint(T, r, c, t, cp[i])) {
-                        adst[cnt] = cdst[i];
-                        for (int k = 0; k < 3; k++) { acp[cnt][k] = cp[i][k]; anr[cnt][k] = n[k]; }
-                        cnt++;
+                    PrimCtx tri;
+                    prim_plane_mask<GTM>(R, xq, xp, P0, n, margin, tri);
+                    unsigned rest = tri.mask;
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                      if (rest) {
+                        const int bit = __builtin_ctz(rest);
+                        rest &= rest - 1;
+                        float dist, cpj[3];
+                        prim_plane_point(tri, n, bit, dist, cpj);
+                        if (gcnt < 4 && terrain_footprint(T, r, c, t, cpj)) {
+                          const int slot = atomicAdd(&S.ncon_ctr, 1);
+                          gcnt++;
+                          if (slot < MC) {
+                            S.cdist[slot] = dist;
+                            S.cgeom[slot] = ln;
+                            S.cpos[slot][0] = cpj[0]; S.cpos[slot][1] = cpj[1]; S.cpos[slot][2] = cpj[2];
+                            if (HF) { S.cnrm[HF ? slot : 0][0] = n[0]; S.cnrm[HF ? slot : 0][1] = n[1]; S.cnrm[HF ? slot : 0][2] = n[2]; }
+                          }
+                        }
                       }
+                    }
                   }
             }
           }
+          WSYNC();
+          ncon = S.ncon_ctr;
         }
-        // compaction in (geom, slot) order
-        int off = 0, total = 0;
-#pragma unroll
-        for (int s2 = 0; s2 < 4; s2++) {
-          unsigned long long mk = __ballot(cnt > s2);
-          off += __popcll(mk & lanemask_lt(ln));
-          total += __popcll(mk);
-        }
-        for (int s2 = 0; s2 < cnt; s2++) {
-          const int slot = off + s2;
-          if (slot < MC) {
-            S.cdist[slot] = adst[s2];
-            S.cgeom[slot] = ln;
-            for (int k = 0; k < 3; k++) { S.cpos[slot][k] = acp[s2][k]; S.cnrm[slot][k] = anr[s2][k]; }
-          }
-        }
-        ncon = total;
         // convex meshes near the ground: all lanes scan the hull (mjc_PlaneConvex against the plane / each candidate triangle)
         unsigned long long mm = __ballot(mesh_near);
         while (mm) {
@@ -875,7 +923,7 @@ __global__ __launch_bounds__(64, RPL == 1 ? 4 : 2) void env_kernel(KArgs A) {
                     if (ncon < MC && ln == 0) {
                       S.cdist[ncon] = dist;
                       S.cgeom[ncon] = g;
-                      for (int k = 0; k < 3; k++) { S.cpos[ncon][k] = cpw[k]; S.cnrm[ncon][k] = n[k]; }
+                      for (int k = 0; k < 3; k++) { S.cpos[ncon][k] = cpw[k]; if (HF) S.cnrm[HF ? ncon : 0][k] = n[k]; }
                     }
                     ncon++;
                     gadded++;
@@ -967,7 +1015,7 @@ __global__ __launch_bounds__(64, RPL == 1 ? 4 : 2) void env_kernel(KArgs A) {
             const LaneRec& G = dm.rec[g];
             const int b = G.g_body;
             const float mu = S.p_gmu[g];
-            float nrm[3] = {S.cnrm[c][0], S.cnrm[c][1], S.cnrm[c][2]}, t1[3], t2[3];
+            float nrm[3] = {HF ? S.cnrm[HF ? c : 0][0] : 0.f, HF ? S.cnrm[HF ? c : 0][1] : 0.f, HF ? S.cnrm[HF ? c : 0][2] : 1.f}, t1[3], t2[3];
             make_frame(nrm, t1, t2);
             const float* tk = (edge >> 1) ? t2 : t1;
             const float sg = (edge & 1) ? -mu : mu;
@@ -1321,8 +1369,7 @@ __global__ __launch_bounds__(64, RPL == 1 ? 4 : 2) void env_kernel(KArgs A) {
         if (ln == 0) { D[8] = (float)niter; D[9] = cost; D[10] = gradnorm; }
         if (ln < NV) { D[1000 + ln] = qacc_l; D[1040 + ln] = S.qcon[ln]; }
         D[1800 + ln] = S.w.r.rowf[ln];
-        if (ln < 4) D[16 + ln] = s_quat[ln];
-        if (ln < 3) { D[20 + ln] = s_gyro[ln]; D[24 + ln] = s_vel[ln]; }
+        if (ln < 10) D[16 + ln] = S.sens[ln];
       }
 
       STAMP(7);   // Newton (sub-phases 10..14 inside)
@@ -1338,7 +1385,7 @@ __global__ __launch_bounds__(64, RPL == 1 ? 4 : 2) void env_kernel(KArgs A) {
             if (dm.rec[g].g_body != ln) continue;
             const float mu = S.p_gmu[g];
             const float* f = &S.w.r.rowf[ne + 4 * c];
-            float nrm[3] = {S.cnrm[c][0], S.cnrm[c][1], S.cnrm[c][2]}, t1[3], t2[3];
+            float nrm[3] = {HF ? S.cnrm[HF ? c : 0][0] : 0.f, HF ? S.cnrm[HF ? c : 0][1] : 0.f, HF ? S.cnrm[HF ? c : 0][2] : 1.f}, t1[3], t2[3];
             make_frame(nrm, t1, t2);
             const float fl0 = f[0] + f[1] + f[2] + f[3], fl1 = (f[0] - f[1]) * mu, fl2 = (f[2] - f[3]) * mu;  // mj_contactForce, pyramidal
             float fw[3], dif[3], tq[3];
@@ -1427,27 +1474,26 @@ __global__ __launch_bounds__(64, RPL == 1 ? 4 : 2) void env_kernel(KArgs A) {
     WSYNC();
     // sensors of the mj_forward at the reset state: zero velocity, IMU orientation from the base quaternion
     {
-      float xq[4] = {S.qpos[3], S.qpos[4], S.qpos[5], S.qpos[6]};
+      float xq[4] = {S.qpos[3], S.qpos[4], S.qpos[5], S.qpos[6]}, sq[4];
       qnorm(xq);
-      qmul(s_quat, xq, dm.imu_quat);
-      qnorm(s_quat);
-      for (int k = 0; k < 3; k++) { s_gyro[k] = 0.f; s_vel[k] = 0.f; }
+      qmul(sq, xq, dm.imu_quat);
+      qnorm(sq);
+      if (lane == 0) { for (int k = 0; k < 4; k++) S.sens[k] = sq[k]; for (int k = 4; k < 10; k++) S.sens[k] = 0.f; }
     }
-    raw_action = 0.f;
-    prev_action = 0.f;
-    tq_lane = 0.f;
+    if (lane < MAXU) { S.act[lane] = 0.f; S.tq[lane] = 0.f; }
     has_prev = 0;
     sim_step = 0;
   }
 
   // =============================================================== _get_obs + _build_state + _apply_command_inplace
   {
+    WSYNC();
     float m[9];
+    const float s_quat[4] = {S.sens[0], S.sens[1], S.sens[2], S.sens[3]};
+    const float s_gyro[3] = {S.sens[4], S.sens[5], S.sens[6]}, s_vel[3] = {S.sens[7], S.sens[8], S.sens[9]};
     q2m(m, s_quat);
     const float pg[3] = {-m[6], -m[7], -m[8]};  // R^T (0,0,-1)
     const bool fill = do_reset;                 // reset fills every stack row with the first frame
-    if (lane < nu) S.act[lane] = raw_action;
-    WSYNC();
     float* so = A.state_out + (size_t)env * ob.state_dim;
     const int sd = ob.stacked_dim, S_ = ob.stack_size;
     for (int e = lane; e < ob.frame_dim; e += 64) {
@@ -1517,10 +1563,12 @@ __global__ __launch_bounds__(64, RPL == 1 ? 4 : 2) void env_kernel(KArgs A) {
   if (A.mode == MODE_STEP) {
     if (A.info != nullptr) {
       float* inf = A.info + (size_t)env * ob.info_dim;
+      const float raw_action = lane < nu ? S.act[lane] : 0.f;
+      const float prev_action = (lane < nu && !do_reset) ? rec[lay.s_lastact + lane] : 0.f;   // still the previous step's action
       float dsq = lane < nu ? (raw_action - prev_action) * (raw_action - prev_action) : 0.f;
       float rmse = sqrtf(wave_sum(dsq) / (float)nu);
-      if (lane == 0) { inf[0] = rmse; inf[1] = s_vel[0]; inf[2] = s_vel[1]; inf[3] = s_gyro[2]; }
-      if (lane < nu) { inf[4 + lane] = tq_lane; inf[4 + nu + lane] = raw_action * dm.rec[lane].a_scale; }
+      if (lane == 0) { inf[0] = rmse; inf[1] = S.sens[7]; inf[2] = S.sens[8]; inf[3] = S.sens[6]; }
+      if (lane < nu) { inf[4 + lane] = S.tq[lane]; inf[4 + nu + lane] = raw_action * dm.rec[lane].a_scale; }
       if (lane < dm.ninfo_state) {
         const LaneRec& R = dm.rec[lane];
         inf[4 + 2 * nu + lane] = (R.i_kind == 0 ? S.qpos[R.i_adr] : S.qvel[R.i_adr]) * R.i_gear;
@@ -1533,7 +1581,7 @@ __global__ __launch_bounds__(64, RPL == 1 ? 4 : 2) void env_kernel(KArgs A) {
     for (int i = 0; i < 16; i++) atomicAdd(reinterpret_cast<unsigned long long*>(A.dbg) + i, pacc[i]);
   if (lane < nq) rec[lay.s_qpos + lane] = S.qpos[lane];
   if (lane < NV) { rec[lay.s_qvel + lane] = S.qvel[lane]; rec[lay.s_warm + lane] = S.qacc[lane]; }
-  if (lane < nu) rec[lay.s_lastact + lane] = do_reset ? 0.f : raw_action;
+  if (lane < nu) rec[lay.s_lastact + lane] = do_reset ? 0.f : S.act[lane];
   if (lane == 0) {
     meta[0] = sim_step; meta[1] = (int)(step_count + 1u); meta[2] = has_prev; meta[4] = nan_resets;
     meta[5] += st_newton; meta[6] += st_ls; meta[7] += st_build; meta[3] += st_rows;
