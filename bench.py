@@ -98,6 +98,8 @@ def main():
     ap.add_argument("--envs-per-gpu", type=int, default=0)
     ap.add_argument("--workload", default="light_flat", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse ranks on one GPU)")
+    ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses cuda:0 (with --backend gloo)")
     args = ap.parse_args()
 
     import torch
@@ -110,8 +112,8 @@ def main():
     if world != args.gpus:
         if args.gpus != 1:
             raise SystemExit(f"--gpus {args.gpus} needs a torch.distributed.run launch with {args.gpus} ranks (WORLD_SIZE={world})")
-    rank, world = init_from_env("nccl")
-    local = int(os.environ.get("LOCAL_RANK", "0"))
+    rank, world = init_from_env(args.backend)
+    local = 0 if args.single_device else int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local)
     robot, terrain, hmap, n_default = WORKLOADS[args.workload]
     n = args.envs_per_gpu or n_default
