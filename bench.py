@@ -98,6 +98,9 @@ def main():
     ap.add_argument("--envs-per-gpu", type=int, default=0)
     ap.add_argument("--workload", default="light_flat", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--streams", type=int, default=1,
+                    help="step the per-GPU fleet as S independent shards on S HIP streams (software pipelining across control "
+                         "steps: one shard's next launch fills the tail of the others'); default 1 = one launch per fleet step")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse ranks on one GPU)")
     ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses cuda:0 (with --backend gloo)")
     args = ap.parse_args()

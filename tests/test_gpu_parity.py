@@ -433,3 +433,45 @@ def test_headless_runner_feeds_a_reporter_like_sink():
     assert len(h["torque"]) == 20 and h["torque"][0].shape == (4,) and len(h["set_points"][0]) == len(h["state"][0])
     assert h["user_command_0"][0] == pytest.approx(0.5) and isinstance(h["action_diff_RMSE"][0], float)
     env.close()
+
+
+def test_position_command_masked_reset_and_push_on_device(parity):
+    """CommandWrapper position mode (wrappers.py:356-375), reset(mask) and event('push') (flamingo_light_v1.py:234-243)."""
+    from cosim_amd.batched_env import BatchedEnv
+    from cosim_amd.compile import compile_model
+    from cosim_amd.config import PARITY_RANDOM, make_config
+    from oracle.envlayer import push_velocity
+    torch = parity["torch"]
+    cfg = make_config("flamingo_light_v1", random=PARITY_RANDOM, position_command=True)
+    cfg["observation"]["command_dim"] = 2
+    cfg["observation"]["command_scales"] = {"0": 2.0, "1": 1.0}
+    env = BatchedEnv(cfg, num_envs=4, auto_reset=False, compiled=compile_model(cfg))
+    assert env.state_dim == 50
+    env.reset()
+    q = np.tile(parity["q0"], (4, 1))
+    q[:, 0:2] = [[1.0, 2.0], [0.0, 0.0], [-3.0, 1.0], [5.0, 5.0]]
+    yaw = np.array([0.5, 0.0, -1.2, 2.0])
+    q[:, 3], q[:, 6] = np.cos(yaw / 2), np.sin(yaw / 2)
+    env.set_state(qpos=q)
+    env.receive_user_command(np.array([3.0, 2.0], dtype=np.float32))          # target in the world frame
+    s, _, _, _ = env.step(torch.zeros((4, 4), device=env.device))
+    got = s[:, 48:50].cpu().numpy()
+    d = np.array([3.0, 2.0])[None] - q[:, 0:2]
+    exp = np.stack([np.cos(-yaw) * d[:, 0] - np.sin(-yaw) * d[:, 1], np.sin(-yaw) * d[:, 0] + np.cos(-yaw) * d[:, 1]], axis=1)
+    np.testing.assert_allclose(got, exp, atol=1e-5)                            # SURVEY App. E poscmd: [1.755, -0.959] for env 0
+    assert got[0] == pytest.approx([1.75516512, -0.95885108], abs=1e-5)
+    # masked reset: only envs 1 and 3 return to the initial pose
+    before = env.get_data().qpos.clone()
+    env.reset(mask=np.array([0, 1, 0, 1], dtype=np.uint8))
+    after = env.get_data().qpos
+    assert torch.equal(after[0], before[0]) and torch.equal(after[2], before[2])
+    assert float(after[1, 2]) == pytest.approx(0.13) and float(after[3, 0]) == 0.0
+    # push: qvel[0:2] = (R^T v)[0:2], qvel[2] = v[2], for the masked envs only
+    v = np.array([0.3, -0.2, 0.1])
+    qp = env.get_data().qpos.cpu().numpy().astype(np.float64)
+    env.event("push", v, mask=np.array([1, 0, 1, 0], dtype=np.uint8))
+    qv = env.get_data().qvel.cpu().numpy()
+    for e in (0, 2):
+        np.testing.assert_allclose(qv[e, 0:3], push_velocity(qp[e], v), atol=1e-6)
+    assert np.abs(qv[1, 0:3]).max() == 0.0
+    env.close()
