@@ -90,6 +90,30 @@ def cpu_baseline(sample_envs=16, sample_steps=12000):
                       f"1 thread of {os.cpu_count()} host cores ({t_total:.1f} s); {ref}"}
 
 
+def pmc_traffic(workload):
+    """HBM bytes per launch of the step kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate
+    passes over this same command: tools/pmc_run.sh -> profiles/r01_pmc_summary_v*.txt).  Counters cannot be read from inside
+    the timed run, so the figure is the one measured for the committed kernel; null for workloads without a PMC pass."""
+    import glob
+    import re
+    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r*_pmc_summary_v*.txt")),
+                   key=lambda f: [int(x) for x in re.findall(r"\d+", os.path.basename(f))])
+    if workload != "light_flat" or not files:
+        return {"traffic": None}
+    vals = {}
+    for line in open(files[-1]):
+        t = line.split()
+        if len(t) >= 3 and t[0] in ("FETCH_SIZE", "WRITE_SIZE"):
+            vals[t[0]] = float(t[2]) * 1024.0                        # rocprofv3 reports both in KiB
+    if len(vals) != 2:
+        return {"traffic": None}
+    return {"traffic": vals["FETCH_SIZE"] + vals["WRITE_SIZE"],
+            "traffic_note": f"bytes per launch, {os.path.basename(files[-1])}: FETCH_SIZE {vals['FETCH_SIZE']:.3g} B (dword-per-lane "
+                            "reads, taken at face value: the guide's x2 gfx950 correction is calibrated for 16-B/lane streaming "
+                            f"reads only) + WRITE_SIZE {vals['WRITE_SIZE']:.3g} B (mostly write-back of the 72 B/lane register-"
+                            "spill scratch)"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -179,7 +203,7 @@ def main():
                                               "ls_evals": st["ls_evals"] / nsub, "factorisations": st["factorisations"] / nsub},
                        "nan_resets": st["nan_resets"]},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, **pmc_traffic(args.workload),
                          "kernel": f"cosim::env_kernel<{env.nv},{env.cm.blob.nbody},...>", "kernel_ms": kernel_ms, "launches": launches,
                          "algorithmic_bytes_per_env_step": balg,
                          "note": "latency/VALU-bound small-state solver; HBM sees only the compulsory state traffic (SURVEY §8d)"},

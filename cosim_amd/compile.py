@@ -72,6 +72,16 @@ def _normalize(v):
 
 
 # ----------------------------------------------------------------------------- compile
+def _hull_centroid(v: np.ndarray) -> np.ndarray:
+    """Volume centroid of the convex hull of `v` (tetrahedra fanned from the vertex mean)."""
+    from scipy.spatial import ConvexHull
+    hull = ConvexHull(v)
+    o = v.mean(0)
+    a, b, c = (v[hull.simplices[:, k]] - o for k in range(3))
+    vol = np.abs(np.einsum("ij,ij->i", a, np.cross(b, c)))           # 6 x tetra volume
+    return o + ((a + b + c) / 4.0 * vol[:, None]).sum(0) / vol.sum()
+
+
 class CompiledModel:
     """ModelBlob plus the side arrays (hull vertices/graph, hfield) and name maps."""
 
@@ -363,6 +373,7 @@ def compile_model(config: dict, model_path: Optional[str] = None) -> CompiledMod
     g_hulladr, g_hullnum = np.zeros(ng, dtype=np.int32), np.zeros(ng, dtype=np.int32)
     g_rbound, g_rcenter = np.zeros(ng), np.zeros((ng, 3))
     g_aabb = np.zeros((ng, 6))
+    g_center = np.zeros((ng, 3))
     for i, g in enumerate(rgeoms):
         rot = quat_to_mat(_normalize(g["quat"]))
         if g["type"] == "mesh":
@@ -379,6 +390,7 @@ def compile_model(config: dict, model_path: Optional[str] = None) -> CompiledMod
             g_rbound[i] = np.linalg.norm(vb.astype(np.float64) - ctr, axis=1).max()
             g_aabb[i, :3] = ctr
             g_aabb[i, 3:] = 0.5 * (vb.astype(np.float64).max(0) - vb.astype(np.float64).min(0))
+            g_center[i] = _hull_centroid(vb.astype(np.float64))
         else:
             g_rcenter[i] = g["pos"]
             s = g["size"]
@@ -394,6 +406,7 @@ def compile_model(config: dict, model_path: Optional[str] = None) -> CompiledMod
                 raise ValueError(f"collision geom type '{g['type']}' not supported")
             g_aabb[i, :3] = g["pos"]
             g_aabb[i, 3:] = g_rbound[i]
+            g_center[i] = g["pos"]
 
     def can_collide(a, b):
         return bool((a["contype"] & b["conaffinity"]) or (b["contype"] & a["conaffinity"]))
@@ -499,6 +512,7 @@ def compile_model(config: dict, model_path: Optional[str] = None) -> CompiledMod
         sf("geom_gap", np.array([g["gap"] for g in rgeoms]))
         sf("geom_rbound", g_rbound)
         sf("geom_rcenter", g_rcenter)
+        sf("geom_center", g_center)
         sf("geom_aabb", g_aabb)
     if len(pairs) > DEFINES["CS_MAXPAIR"]:
         raise ValueError(f"{len(pairs)} self-collision geom pairs exceed the blob capacity")

@@ -97,6 +97,8 @@ typedef struct cosim_model {
   double geom_rbound[CS_MAXGEOM];     /* bounding-sphere radius about geom_rcenter (body frame) */
   double geom_rcenter[CS_MAXGEOM][3];
   double geom_aabb[CS_MAXGEOM][6];    /* body-frame box around the geom: centre xyz, half-extent xyz (broadphase) */
+  double geom_center[CS_MAXGEOM][3];  /* body-frame interior point handed to MPR as the geom centre (mjccd_center: geom_xpos;
+                                         for a mesh MuJoCo's geom frame sits at the mesh CoM = the hull's volume centroid) */
   int pair_geom1[CS_MAXPAIR], pair_geom2[CS_MAXPAIR]; /* robot-robot candidate pairs (self collision) */
 
   /* equality: connect */

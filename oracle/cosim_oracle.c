@@ -40,7 +40,8 @@ enum { CT_EQUALITY = 0, CT_FRICTION, CT_LIMIT, CT_CONTACT };
 
 typedef struct {
   double dist, pos[3], frame[9], friction[5], solref[2], solimp[5], includemargin, mu;
-  int geom, body, dim, efc_address;
+  int geom, body, dim, efc_address; /* geom2 / its body (the "upper" geom of a ground contact) */
+  int geom1, body1;                 /* geom1 = -1, body1 = 0: the static ground */
 } contact_t;
 
 typedef struct oracle_data {
@@ -74,6 +75,7 @@ typedef struct oracle_data {
   int solver_niter, ls_total, bad;
   double solver_cost;
   int contact_overflow;
+  int no_self_collision; /* test switch */
 } oracle_data;
 
 /* ------------------------------------------------------------------ small math (engine_util_*.c) */
@@ -330,6 +332,7 @@ static contact_t* add_contact(oracle_data* d, int geom, double dist, const doubl
   contact_t* c = &d->con[d->ncon++];
   memset(c, 0, sizeof *c);
   c->geom = geom; c->body = d->m.geom_bodyid[geom]; c->dist = dist;
+  c->geom1 = -1; c->body1 = 0;
   memcpy(c->pos, pos, 3 * sizeof(double));
   memcpy(c->frame, normal, 3 * sizeof(double));
   make_frame(c->frame);
@@ -460,27 +463,291 @@ static void plane_mesh(oracle_data* d, int g, const double* ppos, const double* 
   }
 }
 
+
+/* ------------------------------------------------------------------ convex-convex narrowphase: MPR
+ * MuJoCo 3.2.7 sends every geom pair without an analytic routine (here: mesh, cylinder, box pairs, and hfield prisms)
+ * through libccd's ccdMPRPenetration (engine_collision_convex.c mjc_Convex / mjc_ConvexHField -> mjc_MPRIteration;
+ * third-party dependency libccd 2.1, src/mpr.c, absent from /root/reference).  Restated from the published algorithm
+ * (G. Snethen, "XenoCollide", Game Programming Gems 7) following libccd's function structure: discoverPortal /
+ * refinePortal / findPenetr / findPos, its CCD_EPS = DBL_EPSILON predicates, mpr_tolerance = 1e-6 and
+ * max_iterations = 50 (MuJoCo's ccd_tolerance / ccd_iterations defaults).  PARITY UNPINNED (no libccd here). */
+#define CCD_EPS 2.220446049250313e-16
+#define MPR_TOL 1e-6
+#define MPR_MAXIT 50
+#define MPR_REFINE_CAP 1000 /* libccd's refinePortal loop has no cap; this one is never reached in fp64 */
+
+enum { CO_SPHERE = 0, CO_CYLINDER, CO_BOX, CO_MESH, CO_PRISM };
+typedef struct {
+  int kind;
+  double pos[3], mat[9], size[3]; /* primitive: geom world pose; mesh: *body* pose (hull vertices are in body coordinates) */
+  const float* vert; int nvert;
+  double prism[6][3];             /* 0..2 bottom, 3..5 top */
+  double center[3];
+} cobj_t;
+typedef struct { double v[3], v1[3], v2[3]; } csup_t;
+
+static double sign0(double x) { return x > 0 ? 1.0 : (x < 0 ? -1.0 : 0.0); } /* mju_sign */
+static int ccd_zero(double x) { return fabs(x) < CCD_EPS; }
+static int ccd_eq(double a, double b) {
+  double ab = fabs(a - b);
+  if (ab < CCD_EPS) return 1;
+  a = fabs(a); b = fabs(b);
+  return b > a ? ab < CCD_EPS * b : ab < CCD_EPS * a;
+}
+static int vec_eq0(const double* v) { return ccd_eq(v[0], 0) && ccd_eq(v[1], 0) && ccd_eq(v[2], 0); }
+
+/* mjccd_support (engine_collision_convex.c): furthest point of the geom along the unit world direction dir */
+static void co_support(const cobj_t* o, const double* dir, double* out) {
+  double l[3], r[3] = {0, 0, 0};
+  if (o->kind == CO_PRISM) { /* prism support: bottom triangle for dir z < 0, else top */
+    int i0 = dir[2] < 0 ? 0 : 3, best = i0;
+    double bd = dot3(o->prism[i0], dir);
+    for (int i = i0 + 1; i < i0 + 3; i++) { double t = dot3(o->prism[i], dir); if (t > bd) { bd = t; best = i; } }
+    memcpy(out, o->prism[best], 3 * sizeof(double));
+    return;
+  }
+  mul_matT_vec3(l, o->mat, dir);
+  switch (o->kind) {
+    case CO_SPHERE: for (int k = 0; k < 3; k++) r[k] = l[k] * o->size[0]; break;
+    case CO_CYLINDER: {
+      double t = sqrt(l[0] * l[0] + l[1] * l[1]);
+      if (t > MINVAL) { r[0] = l[0] / t * o->size[0]; r[1] = l[1] / t * o->size[0]; }
+      r[2] = sign0(l[2]) * o->size[1];
+    } break;
+    case CO_BOX: for (int k = 0; k < 3; k++) r[k] = sign0(l[k]) * o->size[k]; break;
+    default: { /* mesh: hull vertex with the largest projection (first one on ties) */
+      int best = 0; double bd = -1e300;
+      for (int i = 0; i < o->nvert; i++) {
+        const float* v = o->vert + 3 * i;
+        double t = l[0] * v[0] + l[1] * v[1] + l[2] * v[2];
+        if (t > bd) { bd = t; best = i; }
+      }
+      for (int k = 0; k < 3; k++) r[k] = o->vert[3 * best + k];
+    }
+  }
+  mul_mat_vec3(out, o->mat, r);
+  for (int k = 0; k < 3; k++) out[k] += o->pos[k];
+}
+
+static void mpr_support(const cobj_t* a, const cobj_t* b, const double* dir, csup_t* s) { /* __ccdSupport */
+  double nd[3] = {-dir[0], -dir[1], -dir[2]};
+  co_support(a, dir, s->v1);
+  co_support(b, nd, s->v2);
+  for (int k = 0; k < 3; k++) s->v[k] = s->v1[k] - s->v2[k];
+}
+static void portal_dir(const csup_t* P, double* dir) {
+  double a[3], b[3];
+  for (int k = 0; k < 3; k++) { a[k] = P[2].v[k] - P[1].v[k]; b[k] = P[3].v[k] - P[1].v[k]; }
+  cross3(dir, a, b);
+  normalize3(dir);
+}
+static int portal_reach_tol(const csup_t* P, const csup_t* v4, const double* dir) {
+  double dv1 = dot3(P[1].v, dir), dv2 = dot3(P[2].v, dir), dv3 = dot3(P[3].v, dir), dv4 = dot3(v4->v, dir);
+  double d1 = dv4 - dv1, d2 = dv4 - dv2, d3 = dv4 - dv3;
+  d1 = fmin(d1, fmin(d2, d3));
+  return ccd_eq(d1, MPR_TOL) || d1 < MPR_TOL;
+}
+static void expand_portal(csup_t* P, const csup_t* v4) {
+  double v4v0[3];
+  cross3(v4v0, v4->v, P[0].v);
+  if (dot3(P[1].v, v4v0) > 0) {
+    if (dot3(P[2].v, v4v0) > 0) P[1] = *v4; else P[3] = *v4;
+  } else {
+    if (dot3(P[3].v, v4v0) > 0) P[2] = *v4; else P[1] = *v4;
+  }
+}
+static double point_seg_dist2(const double* x0, const double* b, double* wit) { /* ccdVec3PointSegmentDist2 with P = origin */
+  double dd[3], t;
+  for (int k = 0; k < 3; k++) dd[k] = b[k] - x0[k];
+  t = -dot3(x0, dd) / dot3(dd, dd);
+  if (t < 0 || ccd_zero(t)) { memcpy(wit, x0, 24); return dot3(x0, x0); }
+  if (t > 1 || ccd_eq(t, 1)) { memcpy(wit, b, 24); return dot3(b, b); }
+  for (int k = 0; k < 3; k++) wit[k] = x0[k] + t * dd[k];
+  return dot3(wit, wit);
+}
+static double point_tri_dist2(const double* x0, const double* B, const double* C, double* wit) { /* ccdVec3PointTriDist2, P = origin */
+  double d1[3], d2[3];
+  for (int k = 0; k < 3; k++) { d1[k] = B[k] - x0[k]; d2[k] = C[k] - x0[k]; }
+  double v = dot3(d1, d1), w = dot3(d2, d2), p = dot3(x0, d1), q = dot3(x0, d2), r = dot3(d1, d2);
+  double s = (q * r - w * p) / (w * v - r * r), t = (-s * r - q) / w;
+  if ((ccd_zero(s) || s > 0) && (ccd_eq(s, 1) || s < 1) && (ccd_zero(t) || t > 0) && (ccd_eq(t, 1) || t < 1) &&
+      (ccd_eq(t + s, 1) || t + s < 1)) {
+    for (int k = 0; k < 3; k++) wit[k] = x0[k] + s * d1[k] + t * d2[k];
+    return dot3(wit, wit);
+  }
+  double w2[3], dist = point_seg_dist2(x0, B, wit), dist2 = point_seg_dist2(x0, C, w2);
+  if (dist2 < dist) { dist = dist2; memcpy(wit, w2, 24); }
+  dist2 = point_seg_dist2(B, C, w2);
+  if (dist2 < dist) { dist = dist2; memcpy(wit, w2, 24); }
+  return dist;
+}
+static void mpr_find_pos(const csup_t* P, double* pos) {
+  double dir[3], vec[3], b[4], sum;
+  portal_dir(P, dir);
+  cross3(vec, P[1].v, P[2].v); b[0] = dot3(vec, P[3].v);
+  cross3(vec, P[3].v, P[2].v); b[1] = dot3(vec, P[0].v);
+  cross3(vec, P[0].v, P[1].v); b[2] = dot3(vec, P[3].v);
+  cross3(vec, P[2].v, P[1].v); b[3] = dot3(vec, P[0].v);
+  sum = b[0] + b[1] + b[2] + b[3];
+  if (ccd_zero(sum) || sum < 0) {
+    b[0] = 0;
+    cross3(vec, P[2].v, P[3].v); b[1] = dot3(vec, dir);
+    cross3(vec, P[3].v, P[1].v); b[2] = dot3(vec, dir);
+    cross3(vec, P[1].v, P[2].v); b[3] = dot3(vec, dir);
+    sum = b[1] + b[2] + b[3];
+  }
+  double inv = 1.0 / sum;
+  for (int k = 0; k < 3; k++) {
+    double p1 = 0, p2 = 0;
+    for (int i = 0; i < 4; i++) { p1 += b[i] * P[i].v1[k]; p2 += b[i] * P[i].v2[k]; }
+    pos[k] = 0.5 * (p1 + p2) * inv;
+  }
+}
+
+/* ccdMPRPenetration: 0 = penetrating (depth, dir obj1 -> obj2, pos filled), -1 = separated */
+static int mpr_penetration(const cobj_t* o1, const cobj_t* o2, double* depth, double* dir_out, double* pos) {
+  csup_t P[4], v4;
+  double dir[3], va[3], vb[3], dot;
+  /* --- discoverPortal */
+  for (int k = 0; k < 3; k++) { P[0].v1[k] = o1->center[k]; P[0].v2[k] = o2->center[k]; P[0].v[k] = P[0].v1[k] - P[0].v2[k]; }
+  if (vec_eq0(P[0].v)) P[0].v[0] += CCD_EPS * 10;
+  for (int k = 0; k < 3; k++) dir[k] = -P[0].v[k];
+  normalize3(dir);
+  mpr_support(o1, o2, dir, &P[1]);
+  dot = dot3(P[1].v, dir);
+  if (ccd_zero(dot) || dot < 0) return -1;
+  cross3(dir, P[0].v, P[1].v);
+  if (ccd_zero(dot3(dir, dir))) {
+    if (vec_eq0(P[1].v)) return -1; /* findPenetrTouch: depth 0, dir 0 -> MuJoCo drops the contact (mjc_MPRIteration) */
+    /* findPenetrSegment: origin on the v0-v1 segment */
+    for (int k = 0; k < 3; k++) { pos[k] = 0.5 * (P[1].v1[k] + P[1].v2[k]); dir_out[k] = P[1].v[k]; }
+    *depth = normalize3(dir_out);
+    return 0;
+  }
+  normalize3(dir);
+  mpr_support(o1, o2, dir, &P[2]);
+  dot = dot3(P[2].v, dir);
+  if (ccd_zero(dot) || dot < 0) return -1;
+  for (int k = 0; k < 3; k++) { va[k] = P[1].v[k] - P[0].v[k]; vb[k] = P[2].v[k] - P[0].v[k]; }
+  cross3(dir, va, vb);
+  normalize3(dir);
+  if (dot3(dir, P[0].v) > 0) { csup_t t = P[1]; P[1] = P[2]; P[2] = t; for (int k = 0; k < 3; k++) dir[k] = -dir[k]; }
+  for (int it = 0;; it++) {
+    if (it > MPR_REFINE_CAP) return -1;
+    mpr_support(o1, o2, dir, &P[3]);
+    dot = dot3(P[3].v, dir);
+    if (ccd_zero(dot) || dot < 0) return -1;
+    int cont = 0;
+    cross3(va, P[1].v, P[3].v);
+    dot = dot3(va, P[0].v);
+    if (dot < 0 && !ccd_zero(dot)) { P[2] = P[3]; cont = 1; }
+    if (!cont) {
+      cross3(va, P[3].v, P[2].v);
+      dot = dot3(va, P[0].v);
+      if (dot < 0 && !ccd_zero(dot)) { P[1] = P[3]; cont = 1; }
+    }
+    if (!cont) break;
+    for (int k = 0; k < 3; k++) { va[k] = P[1].v[k] - P[0].v[k]; vb[k] = P[2].v[k] - P[0].v[k]; }
+    cross3(dir, va, vb);
+    normalize3(dir);
+  }
+  /* --- refinePortal */
+  for (int it = 0;; it++) {
+    if (it > MPR_REFINE_CAP) return -1;
+    portal_dir(P, dir);
+    dot = dot3(dir, P[1].v);
+    if (ccd_zero(dot) || dot > 0) break; /* portalEncapsulesOrigin */
+    mpr_support(o1, o2, dir, &v4);
+    dot = dot3(v4.v, dir);
+    if (!(ccd_zero(dot) || dot > 0) || portal_reach_tol(P, &v4, dir)) return -1; /* !portalCanEncapsuleOrigin || tolerance */
+    expand_portal(P, &v4);
+  }
+  /* --- findPenetr */
+  for (int it = 0;; it++) {
+    portal_dir(P, dir);
+    mpr_support(o1, o2, dir, &v4);
+    if (portal_reach_tol(P, &v4, dir) || it > MPR_MAXIT) {
+      double pd[3];
+      *depth = sqrt(point_tri_dist2(P[1].v, P[2].v, P[3].v, pd));
+      if (ccd_zero(pd[0]) && ccd_zero(pd[1]) && ccd_zero(pd[2])) memcpy(pd, dir, 24);
+      normalize3(pd);
+      memcpy(dir_out, pd, 24);
+      mpr_find_pos(P, pos);
+      return 0;
+    }
+    expand_portal(P, &v4);
+  }
+}
+
+static void make_cobj(const oracle_data* d, int g, cobj_t* o) {
+  const cosim_model_t* m = &d->m;
+  int b = m->geom_bodyid[g];
+  double v[3];
+  memset(o, 0, sizeof *o);
+  mul_mat_vec3(v, d->xmat[b], m->geom_center[g]);
+  for (int k = 0; k < 3; k++) o->center[k] = d->xpos[b][k] + v[k];
+  memcpy(o->size, m->geom_size[g], 3 * sizeof(double));
+  switch (m->geom_type[g]) {
+    case CS_GEOM_SPHERE: o->kind = CO_SPHERE; break;
+    case CS_GEOM_CYLINDER: o->kind = CO_CYLINDER; break;
+    case CS_GEOM_BOX: o->kind = CO_BOX; break;
+    default: o->kind = CO_MESH;
+  }
+  if (o->kind == CO_MESH) {
+    memcpy(o->pos, d->xpos[b], 24); memcpy(o->mat, d->xmat[b], 72);
+    o->vert = d->hull_vert + 3 * m->geom_hulladr[g]; o->nvert = m->geom_hullnum[g];
+  } else
+    geom_pose(d, g, o->pos, o->mat);
+}
+
+/* mjc_Convex (engine_collision_convex.c) for one robot-robot pair: a single MPR contact, normal geom1 -> geom2 */
+static void convex_convex(oracle_data* d, int g1, int g2) {
+  const cosim_model_t* m = &d->m;
+  int b1 = m->geom_bodyid[g1], b2 = m->geom_bodyid[g2];
+  double c1[3], c2[3], v[3];
+  mul_mat_vec3(v, d->xmat[b1], m->geom_rcenter[g1]);
+  for (int k = 0; k < 3; k++) c1[k] = d->xpos[b1][k] + v[k];
+  mul_mat_vec3(v, d->xmat[b2], m->geom_rcenter[g2]);
+  for (int k = 0; k < 3; k++) c2[k] = d->xpos[b2][k] + v[k] - c1[k];
+  double margin = fmax(m->geom_margin[g1], m->geom_margin[g2]), rs = m->geom_rbound[g1] + m->geom_rbound[g2] + margin;
+  if (dot3(c2, c2) > rs * rs) return; /* bounding-sphere filter (mj_collideGeoms broadphase: conservative, no effect on results) */
+  cobj_t o1, o2;
+  make_cobj(d, g1, &o1);
+  make_cobj(d, g2, &o2);
+  double depth, dir[3], pos[3];
+  if (mpr_penetration(&o1, &o2, &depth, dir, pos) != 0) return;
+  if (vec_eq0(dir)) return;
+  contact_t* c = add_contact(d, g2, margin - depth, pos, dir);
+  if (c) { c->geom1 = g1; c->body1 = b1; }
+}
+
 /* mj_contactParam (engine_collision_driver.c): equal priority -> solmix weighting, friction = elementwise max */
 static void contact_param(const oracle_data* d, contact_t* c) {
   const cosim_model_t* m = &d->m;
-  int g = c->geom;
+  int g = c->geom, h = c->geom1;
+  /* geom1 parameters: the ground's when h < 0 */
+  double s1 = h < 0 ? m->ground_solmix : m->geom_solmix[h], s2 = m->geom_solmix[g];
+  int cd1 = h < 0 ? m->ground_condim : m->geom_condim[h];
+  const double* sr1 = h < 0 ? m->ground_solref : m->geom_solref[h];
+  const double* si1 = h < 0 ? m->ground_solimp : m->geom_solimp[h];
+  const double* fr1 = h < 0 ? m->ground_friction : m->geom_friction[h];
+  double mg1 = h < 0 ? m->ground_margin : m->geom_margin[h], gp1 = h < 0 ? m->ground_gap : m->geom_gap[h];
   double mix;
-  double s1 = m->ground_solmix, s2 = m->geom_solmix[g];
   if (s1 >= MINVAL && s2 >= MINVAL) mix = s1 / (s1 + s2);
   else if (s1 < MINVAL && s2 < MINVAL) mix = 0.5;
   else mix = s1 < MINVAL ? 0.0 : 1.0;
-  c->dim = m->ground_condim > m->geom_condim[g] ? m->ground_condim : m->geom_condim[g];
-  if (m->ground_solref[0] > 0 && m->geom_solref[g][0] > 0)
-    for (int k = 0; k < 2; k++) c->solref[k] = mix * m->ground_solref[k] + (1 - mix) * m->geom_solref[g][k];
+  c->dim = cd1 > m->geom_condim[g] ? cd1 : m->geom_condim[g];
+  if (sr1[0] > 0 && m->geom_solref[g][0] > 0)
+    for (int k = 0; k < 2; k++) c->solref[k] = mix * sr1[k] + (1 - mix) * m->geom_solref[g][k];
   else
-    for (int k = 0; k < 2; k++) c->solref[k] = fmin(m->ground_solref[k], m->geom_solref[g][k]);
-  for (int k = 0; k < 5; k++) c->solimp[k] = mix * m->ground_solimp[k] + (1 - mix) * m->geom_solimp[g][k];
+    for (int k = 0; k < 2; k++) c->solref[k] = fmin(sr1[k], m->geom_solref[g][k]);
+  for (int k = 0; k < 5; k++) c->solimp[k] = mix * si1[k] + (1 - mix) * m->geom_solimp[g][k];
   double fr[3];
-  for (int k = 0; k < 3; k++) fr[k] = fmax(m->ground_friction[k], m->geom_friction[g][k]);
+  for (int k = 0; k < 3; k++) fr[k] = fmax(fr1[k], m->geom_friction[g][k]);
   c->friction[0] = c->friction[1] = fmax(MINMU, fr[0]);
   c->friction[2] = fmax(MINMU, fr[1]);
   c->friction[3] = c->friction[4] = fmax(MINMU, fr[2]);
-  double margin = fmax(m->ground_margin, m->geom_margin[g]), gap = fmax(m->ground_gap, m->geom_gap[g]);
+  double margin = fmax(mg1, m->geom_margin[g]), gap = fmax(gp1, m->geom_gap[g]);
   c->includemargin = margin - gap;
 }
 
@@ -505,6 +772,12 @@ static void collision(oracle_data* d) {
       }
     } else
       hfield_collide(d, g);
+    for (int i = first; i < d->ncon; i++) contact_param(d, &d->con[i]);
+  }
+  /* robot-robot pairs that pass the contype/conaffinity, same-body, parent-child and <exclude> filters (compiled list) */
+  for (int p = 0; p < m->npair && !d->no_self_collision; p++) {
+    int first = d->ncon;
+    convex_convex(d, m->pair_geom1[p], m->pair_geom2[p]);
     for (int i = first; i < d->ncon; i++) contact_param(d, &d->con[i]);
   }
 }
@@ -683,10 +956,16 @@ static void make_constraint(oracle_data* d) {
     c->efc_address = -1;
     if (c->dist >= c->includemargin) continue;
     double jp[3][NV], jf[3][NV];
-    jac_point(d, c->body, c->pos, jp); /* geom1 is the static ground: jacdif = jac(body2) */
+    jac_point(d, c->body, c->pos, jp); /* mj_jacDifPair: jac(body2) - jac(body1); the ground (world body) contributes 0 */
+    if (c->body1 > 0) {
+      double j1[3][NV];
+      jac_point(d, c->body1, c->pos, j1);
+      for (int r = 0; r < 3; r++)
+        for (int k = 0; k < nv; k++) jp[r][k] -= j1[r][k];
+    }
     for (int r = 0; r < 3; r++)
       for (int k = 0; k < nv; k++) jf[r][k] = c->frame[3 * r] * jp[0][k] + c->frame[3 * r + 1] * jp[1][k] + c->frame[3 * r + 2] * jp[2][k];
-    double tran = m->body_invweight0[c->body][0]; /* world body contributes 0 */
+    double tran = m->body_invweight0[c->body][0] + m->body_invweight0[c->body1][0]; /* world body contributes 0 */
     c->efc_address = d->nefc;
     if (c->dim == 1) {
       int r = add_row(d, CT_CONTACT, ci, c->dist, c->includemargin, 0, tran);
@@ -1192,6 +1471,8 @@ void oracle_cfrc_ext(oracle_data* d) {
     for (int k = 0; k < 3; k++) dif[k] = c->pos[k] - d->subtree_com[m->body_rootid[c->body]][k];
     cross3(tq, dif, fw);
     for (int k = 0; k < 3; k++) { d->cfrc_ext[c->body][k] += tq[k]; d->cfrc_ext[c->body][3 + k] += fw[k]; }
+    if (c->body1 > 0) /* mj_rnePostConstraint: equal and opposite on geom1's body */
+      for (int k = 0; k < 3; k++) { d->cfrc_ext[c->body1][k] -= tq[k]; d->cfrc_ext[c->body1][3 + k] -= fw[k]; }
   }
 }
 
@@ -1244,13 +1525,22 @@ int oracle_int(oracle_data* d, const char* name) {
   if (!strcmp(name, "nvmax")) return NV;
   return -1;
 }
-/* contact i -> [dist, pos3, normal3, geom, efc_address] */
+/* contact i -> [dist, pos3, normal3, geom, efc_address, geom1] */
 void oracle_contact(oracle_data* d, int i, double* out) {
   const contact_t* c = &d->con[i];
   out[0] = c->dist;
   for (int k = 0; k < 3; k++) { out[1 + k] = c->pos[k]; out[4 + k] = c->frame[k]; }
-  out[7] = c->geom; out[8] = c->efc_address;
+  out[7] = c->geom; out[8] = c->efc_address; out[9] = c->geom1;
 }
+
+/* test hooks: one MPR query between two robot geoms (returns 0 when penetrating); self-collision switch */
+int oracle_mpr_pair(oracle_data* d, int g1, int g2, double* out7) {
+  cobj_t o1, o2;
+  make_cobj(d, g1, &o1);
+  make_cobj(d, g2, &o2);
+  return mpr_penetration(&o1, &o2, out7, out7 + 1, out7 + 4);
+}
+void oracle_set_self_collision(oracle_data* d, int on) { d->no_self_collision = !on; }
 
 /* One control step of the robot-env layer (reference flamingo_light_v1.py:131-154): PD torque from the (already
    delay-filtered) action, held over frame_skip substeps.  Returns the applied torques in tq[nu]. */
