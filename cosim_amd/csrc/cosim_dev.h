@@ -52,7 +52,7 @@ struct LaneRec {
 static_assert(sizeof(LaneRec) == 512, "LaneRec must stay 512 bytes (immediate-offset addressing)");
 
 struct DevModel {
-  int nq, nv, nu, nbody, njnt, ngeom, neq, nfric;
+  int nq, nv, nu, nbody, njnt, ngeom, neq, nfric, npair;
   int frame_skip, iterations, ls_iterations, maxdepth;
   int ground_type, hfield_nrow, hfield_ncol, nhullvert;
   int imu_body, term_mode, nterm_body, ntri;

@@ -35,6 +35,8 @@ struct cosim_engine {
   DevObs* d_obs = nullptr;
   float *d_state = nullptr, *d_params = nullptr, *d_hull_vert = nullptr, *d_hfield = nullptr, *d_dbg = nullptr;
   int *d_hull_adr = nullptr, *d_hull_nbr = nullptr;
+  unsigned* d_pairs = nullptr;   // robot-robot candidate pairs (geom1 | geom2 << 16)
+  float4* d_gext = nullptr;      // per geom: MPR centre (body frame), raw sliding friction
   std::vector<float> h_params;
   bool params_dirty = true;
   uint64_t seed = 0;
@@ -53,18 +55,18 @@ struct cosim_engine {
   int lds_bytes = 0;
 };
 
-template <int NV, int NB, int RPL, bool HF, int GTM>
+template <int NV, int NB, int RPL, bool HF, int GTM, bool SC>
 static void launch_t(cosim_engine* e, const KArgs& a, int grid, hipStream_t s) {
-  hipLaunchKernelGGL((env_kernel<NV, NB, RPL, HF, GTM>), dim3(grid), dim3(64), 0, s, a);
+  hipLaunchKernelGGL((env_kernel<NV, NB, RPL, HF, GTM, SC>), dim3(grid), dim3(64), 0, s, a);
 }
 template <int NV, int NB, int RPL, int GTM>
 static void launch_prof_t(cosim_engine* e, const KArgs& a, int grid, hipStream_t s) {
-  hipLaunchKernelGGL((env_kernel<NV, NB, RPL, false, GTM, true>), dim3(grid), dim3(64), 0, s, a);
+  hipLaunchKernelGGL((env_kernel<NV, NB, RPL, false, GTM, false, true>), dim3(grid), dim3(64), 0, s, a);
 }
-template <int NV, int NB, int RPL, int GTM>
+template <int NV, int NB, int RPL, int GTM, bool SC>
 static void select_t(cosim_engine* e, bool hf) {
-  e->launch = hf ? launch_t<NV, NB, RPL, true, GTM> : launch_t<NV, NB, RPL, false, GTM>;
-  e->lds_bytes = hf ? (int)sizeof(EnvLds<NV, NB, RPL, true>) : (int)sizeof(EnvLds<NV, NB, RPL, false>);
+  e->launch = hf ? launch_t<NV, NB, RPL, true, GTM, SC> : launch_t<NV, NB, RPL, false, GTM, SC>;
+  e->lds_bytes = (hf || SC) ? (int)sizeof(EnvLds<NV, NB, RPL, true>) : (int)sizeof(EnvLds<NV, NB, RPL, false>);
 }
 
 static int round_up(int x, int m) { return (x + m - 1) / m * m; }
@@ -73,7 +75,7 @@ static int build_dev_model(cosim_engine* e) {
   const cosim_model_t& m = e->model;
   DevModel& d = e->hm;
   memset(&d, 0, sizeof d);
-  d.nq = m.nq; d.nv = m.nv; d.nu = m.nu; d.nbody = m.nbody; d.njnt = m.njnt; d.ngeom = m.ngeom; d.neq = m.neq;
+  d.nq = m.nq; d.nv = m.nv; d.nu = m.nu; d.nbody = m.nbody; d.njnt = m.njnt; d.ngeom = m.ngeom; d.neq = m.neq; d.npair = m.npair;
   d.frame_skip = m.frame_skip; d.iterations = m.iterations; d.ls_iterations = m.ls_iterations;
   d.ground_type = m.ground_type; d.hfield_nrow = m.hfield_nrow; d.hfield_ncol = m.hfield_ncol; d.nhullvert = m.nhullvert;
   d.imu_body = m.imu_bodyid; d.term_mode = m.term_mode; d.nterm_body = m.nterm_body;
@@ -309,8 +311,10 @@ int cosim_create(const cosim_model_t* model, const float* hull_vert, const int* 
   // kernel instantiations: (nv, nbody) of the four cosim robots; RPL = constraint rows per lane
   const bool hf = model->ground_type == CS_GEOM_HFIELD;
   int gtm = 0;   // geom types present: the kernel is specialised on them (bit 0 sphere, 1 cylinder, 2 box, 3 mesh)
+  std::vector<char> in_pair(model->ngeom > 0 ? model->ngeom : 1, 0);
+  for (int p = 0; p < model->npair; p++) { in_pair[model->pair_geom1[p]] = 1; in_pair[model->pair_geom2[p]] = 1; }
   for (int g = 0; g < model->ngeom; g++) {
-    if (!model->geom_ground[g]) continue;
+    if (!model->geom_ground[g] && !in_pair[g]) continue;
     switch (model->geom_type[g]) {
       case CS_GEOM_SPHERE: gtm |= GT_SPHERE; break;
       case CS_GEOM_CYLINDER: gtm |= GT_CYLINDER; break;
@@ -320,10 +324,10 @@ int cosim_create(const cosim_model_t* model, const float* hull_vert, const int* 
     }
   }
   constexpr int G_LIGHT = GT_SPHERE | GT_CYLINDER | GT_MESH, G_MESH = GT_MESH, G_HUM = GT_BOX | GT_CYLINDER | GT_MESH;
-  if (nv == 18 && nb <= 14 && (gtm & ~G_LIGHT) == 0) { select_t<18, 14, 1, G_LIGHT>(e, hf); if (!hf) e->launch_prof = launch_prof_t<18, 14, 1, G_LIGHT>; }   // flamingo_light_v1
-  else if (nv == 14 && nb <= 10 && (gtm & ~G_MESH) == 0) select_t<14, 10, 2, G_MESH>(e, hf);   // flamingo_p_v3
-  else if (nv == 22 && nb <= 18 && (gtm & ~G_MESH) == 0) select_t<22, 18, 2, G_MESH>(e, hf);   // w4_p_v2
-  else if (nv == 29 && nb <= 26 && (gtm & ~G_HUM) == 0) select_t<29, 26, 2, G_HUM>(e, hf);     // humanoid_p_v0
+  if (nv == 18 && nb <= 14 && (gtm & ~G_LIGHT) == 0) { select_t<18, 14, 1, G_LIGHT, false>(e, hf); if (!hf) e->launch_prof = launch_prof_t<18, 14, 1, G_LIGHT>; }   // flamingo_light_v1
+  else if (nv == 14 && nb <= 10 && (gtm & ~G_MESH) == 0) select_t<14, 10, 2, G_MESH, true>(e, hf);   // flamingo_p_v3
+  else if (nv == 22 && nb <= 18 && (gtm & ~G_MESH) == 0) select_t<22, 18, 2, G_MESH, true>(e, hf);   // w4_p_v2
+  else if (nv == 29 && nb <= 26 && (gtm & ~G_HUM) == 0) select_t<29, 26, 2, G_HUM, true>(e, hf);     // humanoid_p_v0
   else { delete e; return fail(COSIM_EINVAL, "cosim_create: no kernel instantiation for this (nv, nbody); add one in cosim_engine.hip"); }
   HIP_TRY(hipMalloc(&e->d_model, sizeof(DevModel)));
   HIP_TRY(hipMalloc(&e->d_obs, sizeof(DevObs)));
@@ -343,6 +347,17 @@ int cosim_create(const cosim_model_t* model, const float* hull_vert, const int* 
     HIP_TRY(hipMemcpy(e->d_hull_adr, hull_adr, (size_t)(model->nhullvert + 1) * sizeof(int), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(e->d_hull_nbr, hull_nbr, (size_t)model->nhulledge * sizeof(int), hipMemcpyHostToDevice));
   }
+  {
+    std::vector<unsigned> hp(model->npair > 0 ? model->npair : 1, 0u);
+    for (int p = 0; p < model->npair; p++) hp[p] = (unsigned)model->pair_geom1[p] | ((unsigned)model->pair_geom2[p] << 16);
+    std::vector<float4> hg(model->ngeom > 0 ? model->ngeom : 1);
+    for (int g = 0; g < model->ngeom; g++)
+      hg[g] = make_float4((float)model->geom_center[g][0], (float)model->geom_center[g][1], (float)model->geom_center[g][2], (float)model->geom_friction[g][0]);
+    HIP_TRY(hipMalloc(&e->d_pairs, hp.size() * sizeof(unsigned)));
+    HIP_TRY(hipMalloc(&e->d_gext, hg.size() * sizeof(float4)));
+    HIP_TRY(hipMemcpy(e->d_pairs, hp.data(), hp.size() * sizeof(unsigned), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(e->d_gext, hg.data(), hg.size() * sizeof(float4), hipMemcpyHostToDevice));
+  }
   if (model->ground_type == CS_GEOM_HFIELD) {
     if (!hfield) return fail(COSIM_EINVAL, "cosim_create: heightfield ground but no elevation data was passed");
     size_t nh = (size_t)model->hfield_nrow * model->hfield_ncol;
@@ -359,6 +374,7 @@ int cosim_destroy(cosim_engine_t* e) {
   hipSetDevice(e->device);
   hipFree(e->d_model); hipFree(e->d_obs); hipFree(e->d_state); hipFree(e->d_params); hipFree(e->d_dbg);
   hipFree(e->d_hull_vert); hipFree(e->d_hull_adr); hipFree(e->d_hull_nbr); hipFree(e->d_hfield);
+  hipFree(e->d_pairs); hipFree(e->d_gext);
   for (hipEvent_t x : e->ev) hipEventDestroy(x);
   delete e;
   return COSIM_OK;
@@ -426,6 +442,7 @@ static KArgs base_args(cosim_engine* e) {
   memset(&a, 0, sizeof a);
   a.dm = e->d_model; a.ob = e->d_obs; a.lay = e->lay; a.state = e->d_state; a.params = e->d_params;
   a.hull_vert = e->d_hull_vert; a.hull_adr = e->d_hull_adr; a.hull_nbr = e->d_hull_nbr; a.hfield = e->d_hfield;
+  a.pairs = e->d_pairs; a.gext = e->d_gext;
   a.n_envs = e->n_envs; a.seed_lo = (unsigned)e->seed; a.seed_hi = (unsigned)(e->seed >> 32); a.env_id0 = e->env_id0;
   a.tol32 = e->tol32; a.max_newton = e->max_newton; a.max_ls = e->max_ls;
   return a;

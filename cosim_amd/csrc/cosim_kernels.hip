@@ -28,6 +28,7 @@ namespace cosim {
 #define LAUNDER(x) asm volatile("" : "+v"(x))
 
 constexpr float MINVAL = 1e-15f;
+constexpr float MINMU = 1e-5f;
 constexpr float MINIMP = 0.0001f, MAXIMP = 0.9999f;
 
 enum { RT_NONE = -1, RT_EQ = 0, RT_CONTACT = 1, RT_FRIC = 2, RT_LIMIT = 3 };
@@ -43,6 +44,8 @@ struct KArgs {
   const int* hull_adr;
   const int* hull_nbr;
   const float* hfield;
+  const unsigned* pairs;  // robot-robot candidate pairs: geom1 | geom2 << 16
+  const float4* gext;     // per geom: MPR centre (body frame) xyz, raw sliding friction w
   const float* actions;   // [N, nu]
   const float* commands;  // [N, command_dim]
   float* state_out;       // [N, state_dim]
@@ -157,7 +160,7 @@ __device__ __forceinline__ unsigned philox_first(unsigned k0, unsigned k1, unsig
 __device__ __forceinline__ float u01(unsigned x) { return (float)(x >> 8) * (1.0f / 16777216.0f) + (0.5f / 16777216.0f); }  // (0,1)
 
 // ------------------------------------------------------------------------------------------------ LDS per env
-template <int NV, int NB, int RPL, bool HF>
+template <int NV, int NB, int RPL, bool NRM>   // NRM: contact normals are stored (heightfield ground or robot-robot pairs)
 struct EnvLds {
   static constexpr int LD = NV | 1;   // odd leading dimension: conflict-free column access
   static constexpr int ROWS = 64 * RPL;            // constraint rows per env: RPL rows per lane
@@ -177,8 +180,8 @@ struct EnvLds {
     struct { float rowf[ROWS], rowD[ROWS]; } r;
   } w;
   float J[NGEN][LD];
-  float cpos[MC][3], cnrm[HF ? MC : 1][3], cdist[MC];   // contact normals are +z on the plane: not stored
-  int cgeom[MC];
+  float cpos[MC][3], cnrm[NRM ? MC : 1][3], cdist[MC];   // contact normals are +z on the plane: not stored
+  int cgeom[MC];   // geom2 | (geom1 + 1) << 8; geom1 + 1 == 0: the ground
   int lim_body[NLIM];
   float lim_sign[NLIM], lim_dist[NLIM];
   float p_mass[NB], p_binvw[NB], p_dinvw[NV], p_floss[NV], p_gmu[32];
@@ -370,6 +373,9 @@ __device__ __forceinline__ float terrain_height(const Terrain& T, float x, float
   return T.gz + T.sz * hh;
 }
 
+}  // namespace cosim
+#include "cosim_mpr.h"
+namespace cosim {
 // ------------------------------------------------------------------------------------------------ impedance (mj_makeImpedance)
 __device__ __forceinline__ float impedance(const float* solimp, float pos, float margin) {
   float d0 = fminf(MAXIMP, fmaxf(MINIMP, solimp[0])), d1 = fminf(MAXIMP, fmaxf(MINIMP, solimp[1]));
@@ -387,9 +393,11 @@ __device__ __forceinline__ float impedance(const float* solimp, float pos, float
 }
 
 // ------------------------------------------------------------------------------------------------ the kernel
-template <int NV, int NB, int RPL, bool HF, int GTM, bool PROF = false>   // HF: heightfield ground; PROF: diagnostic build with s_memtime phase stamps
+// HF: heightfield ground; SC: robot-robot (self) collision pairs; PROF: diagnostic build with s_memtime phase stamps
+template <int NV, int NB, int RPL, bool HF, int GTM, bool SC, bool PROF = false>
 __global__ __launch_bounds__(64, RPL == 1 ? 4 : 2) void env_kernel(KArgs A) {
-  using L = EnvLds<NV, NB, RPL, HF>;
+  constexpr bool NRM = HF || SC;
+  using L = EnvLds<NV, NB, RPL, NRM>;
   constexpr int MAXROWS = L::ROWS;
   constexpr int TRI = NV * (NV + 1) / 2;
   constexpr int MC = L::MC;
@@ -815,6 +823,7 @@ __global__ __launch_bounds__(64, RPL == 1 ? 4 : 2) void env_kernel(KArgs A) {
                   S.cdist[slot] = dist;
                   S.cgeom[slot] = ln;
                   S.cpos[slot][0] = pnt[0]; S.cpos[slot][1] = pnt[1]; S.cpos[slot][2] = pnt[2];
+                  if (NRM) { S.cnrm[NRM ? slot : 0][0] = 0.f; S.cnrm[NRM ? slot : 0][1] = 0.f; S.cnrm[NRM ? slot : 0][2] = 1.f; }
                 }
               }
             }
@@ -853,7 +862,7 @@ __global__ __launch_bounds__(64, RPL == 1 ? 4 : 2) void env_kernel(KArgs A) {
                             S.cdist[slot] = dist;
                             S.cgeom[slot] = ln;
                             S.cpos[slot][0] = cpj[0]; S.cpos[slot][1] = cpj[1]; S.cpos[slot][2] = cpj[2];
-                            if (HF) { S.cnrm[HF ? slot : 0][0] = n[0]; S.cnrm[HF ? slot : 0][1] = n[1]; S.cnrm[HF ? slot : 0][2] = n[2]; }
+                            if (NRM) { S.cnrm[NRM ? slot : 0][0] = n[0]; S.cnrm[NRM ? slot : 0][1] = n[1]; S.cnrm[NRM ? slot : 0][2] = n[2]; }
                           }
                         }
                       }
@@ -923,13 +932,103 @@ __global__ __launch_bounds__(64, RPL == 1 ? 4 : 2) void env_kernel(KArgs A) {
                     if (ncon < MC && ln == 0) {
                       S.cdist[ncon] = dist;
                       S.cgeom[ncon] = g;
-                      for (int k = 0; k < 3; k++) { S.cpos[ncon][k] = cpw[k]; if (HF) S.cnrm[HF ? ncon : 0][k] = n[k]; }
+                      for (int k = 0; k < 3; k++) { S.cpos[ncon][k] = cpw[k]; if (NRM) S.cnrm[NRM ? ncon : 0][k] = n[k]; }
                     }
                     ncon++;
                     gadded++;
                   }
                 }
               }
+        }
+      }
+
+      if constexpr (SC) {
+        // =========================================================== robot-robot pairs (mjc_Convex: one MPR contact per pair)
+        // candidates: the compiled pair list (contype/conaffinity, same-body, parent-child and <exclude> filters applied)
+        // cut down by bounding spheres; primitive pairs run lane-parallel, pairs with a mesh one at a time wave-wide
+        auto make_cobj = [&](CObj& o, int g) {
+          const LaneRec& G = dm.rec[g];
+          const int gb = G.g_body;
+          const float bq[4] = {S.xquat[gb][0], S.xquat[gb][1], S.xquat[gb][2], S.xquat[gb][3]};
+          const float4 ge = A.gext[g];
+          const float cl[3] = {ge.x, ge.y, ge.z};
+          float v[3];
+          qrot(v, bq, cl);
+          for (int k = 0; k < 3; k++) o.center[k] = S.xpos[gb][k] + v[k];
+          o.kind = G.g_type; o.adr = G.g_hulladr; o.num = G.g_hullnum;
+          for (int k = 0; k < 3; k++) o.size[k] = G.g_size[k];
+          if (G.g_type == CS_GEOM_MESH) {
+            for (int k = 0; k < 3; k++) o.pos[k] = S.xpos[gb][k];
+            for (int k = 0; k < 4; k++) o.q[k] = bq[k];
+          } else {
+            qrot(v, bq, G.g_pos);
+            for (int k = 0; k < 3; k++) o.pos[k] = S.xpos[gb][k] + v[k];
+            qmul(o.q, bq, G.g_quat);
+          }
+        };
+        const int npair = dm.npair;
+        for (int p0 = 0; p0 < npair; p0 += 64) {
+          const int p = p0 + ln;
+          bool cand = false, mesh = false;
+          int g1 = 0, g2 = 0;
+          if (p < npair) {
+            const unsigned pk = A.pairs[p];
+            g1 = pk & 0xffffu; g2 = pk >> 16;
+            const LaneRec &G1 = dm.rec[g1], &G2 = dm.rec[g2];
+            const float q1[4] = {S.xquat[G1.g_body][0], S.xquat[G1.g_body][1], S.xquat[G1.g_body][2], S.xquat[G1.g_body][3]};
+            const float q2[4] = {S.xquat[G2.g_body][0], S.xquat[G2.g_body][1], S.xquat[G2.g_body][2], S.xquat[G2.g_body][3]};
+            float v1[3], v2[3];
+            qrot(v1, q1, G1.g_rcenter);
+            qrot(v2, q2, G2.g_rcenter);
+            float d2 = 0.f;
+            for (int k = 0; k < 3; k++) { const float dk = (S.xpos[G2.g_body][k] + v2[k]) - (S.xpos[G1.g_body][k] + v1[k]); d2 += dk * dk; }
+            const float rs = G1.g_rbound + G2.g_rbound + fmaxf(G1.g_margin, G2.g_margin);
+            cand = d2 <= rs * rs;
+            mesh = cand && (G1.g_type == CS_GEOM_MESH || G2.g_type == CS_GEOM_MESH);
+          }
+          bool hit = false;
+          float depth = 0.f, cn[3] = {0.f, 0.f, 1.f}, cp[3] = {0.f, 0.f, 0.f};
+          if constexpr ((GTM & ~GT_MESH) != 0) {
+            if (cand && !mesh) {
+              CObj o1, o2;
+              make_cobj(o1, g1);
+              make_cobj(o2, g2);
+              const MprPair<GTM, false> sup{o1, o2, A.hull_vert, ln};
+              hit = mpr_penetration(sup, o1.center, o2.center, depth, cn, cp) && !mpr_vzero(cn);
+            }
+          }
+          {
+            const unsigned long long hm = __ballot(hit);
+            const int slot = ncon + __popcll(hm & lanemask_lt(ln));
+            if (hit && slot < MC) {
+              S.cdist[slot] = -depth;
+              S.cgeom[slot] = g2 | ((g1 + 1) << 8);
+              for (int k = 0; k < 3; k++) { S.cpos[slot][k] = cp[k]; S.cnrm[NRM ? slot : 0][k] = cn[k]; }
+            }
+            ncon += __popcll(hm);
+          }
+          if constexpr ((GTM & GT_MESH) != 0) {
+            unsigned long long mm = __ballot(mesh);
+            while (mm) {
+              const int src = __builtin_ctzll(mm);
+              mm &= mm - 1;
+              const int h1 = __shfl(g1, src, 64), h2 = __shfl(g2, src, 64);
+              CObj o1, o2;
+              make_cobj(o1, h1);
+              make_cobj(o2, h2);
+              const MprPair<GTM, true> sup{o1, o2, A.hull_vert, ln};
+              float dep2 = 0.f, n2[3] = {0.f, 0.f, 1.f}, c2[3] = {0.f, 0.f, 0.f};
+              const bool hit2 = mpr_penetration(sup, o1.center, o2.center, dep2, n2, c2) && !mpr_vzero(n2);
+              if (hit2) {
+                if (ln == 0 && ncon < MC) {
+                  S.cdist[ncon] = -dep2;
+                  S.cgeom[ncon] = h2 | ((h1 + 1) << 8);
+                  for (int k = 0; k < 3; k++) { S.cpos[ncon][k] = c2[k]; S.cnrm[NRM ? ncon : 0][k] = n2[k]; }
+                }
+                ncon++;
+              }
+            }
+          }
         }
       }
 
@@ -1011,25 +1110,28 @@ __global__ __launch_bounds__(64, RPL == 1 ? 4 : 2) void env_kernel(KArgs A) {
           } else {
             rtype[rr] = RT_CONTACT;
             const int c = (row - ne) >> 2, edge = (row - ne) & 3;
-            const int g = S.cgeom[c];
+            const int gg = S.cgeom[c], g = gg & 0xff, g1 = (gg >> 8) - 1;   // g1 < 0: geom1 is the ground
             const LaneRec& G = dm.rec[g];
-            const int b = G.g_body;
-            const float mu = S.p_gmu[g];
-            float nrm[3] = {HF ? S.cnrm[HF ? c : 0][0] : 0.f, HF ? S.cnrm[HF ? c : 0][1] : 0.f, HF ? S.cnrm[HF ? c : 0][2] : 1.f}, t1[3], t2[3];
+            const int b = G.g_body, b1 = (SC && g1 >= 0) ? dm.rec[g1].g_body : 0;
+            const float mu = (SC && g1 >= 0) ? fmaxf(MINMU, fmaxf(A.gext[g].w, A.gext[g1].w)) : S.p_gmu[g];
+            float nrm[3] = {NRM ? S.cnrm[NRM ? c : 0][0] : 0.f, NRM ? S.cnrm[NRM ? c : 0][1] : 0.f, NRM ? S.cnrm[NRM ? c : 0][2] : 1.f}, t1[3], t2[3];
             make_frame(nrm, t1, t2);
             const float* tk = (edge >> 1) ? t2 : t1;
             const float sg = (edge & 1) ? -mu : mu;
             float dir[3] = {nrm[0] + sg * tk[0], nrm[1] + sg * tk[1], nrm[2] + sg * tk[2]};
             float off[3] = {S.cpos[c][0] - com[0], S.cpos[c][1] - com[1], S.cpos[c][2] - com[2]}, od[3];
             cross(od, off, dir);
-            for (unsigned mk = dm.rec[b].b_dofmask; mk; mk &= mk - 1) {
+            // mj_jacDifPair: jac(body2) - jac(body1); dofs common to both chains cancel
+            const unsigned m2 = dm.rec[b].b_dofmask, m1 = (SC && g1 >= 0) ? dm.rec[b1].b_dofmask : 0u;
+            for (unsigned mk = m2 ^ m1; mk; mk &= mk - 1) {
               const int j = __builtin_ctz(mk);
-              Jr[j] = dir[0] * S.cdof[j][3] + dir[1] * S.cdof[j][4] + dir[2] * S.cdof[j][5] + od[0] * S.cdof[j][0] + od[1] * S.cdof[j][1] + od[2] * S.cdof[j][2];
+              const float jv = dir[0] * S.cdof[j][3] + dir[1] * S.cdof[j][4] + dir[2] * S.cdof[j][5] + od[0] * S.cdof[j][0] + od[1] * S.cdof[j][1] + od[2] * S.cdof[j][2];
+              Jr[j] = ((m2 >> j) & 1u) ? jv : -jv;
             }
             rpos = S.cdist[c];
             rmargin = G.g_incmargin;
             rmu = mu;
-            rdiagA = S.p_binvw[b] * (1.f + mu * mu);
+            rdiagA = (S.p_binvw[b] + ((SC && g1 >= 0) ? S.p_binvw[b1] : 0.f)) * (1.f + mu * mu);
             for (int k = 0; k < 2; k++) rsolref[k] = G.g_solref[k];
             for (int k = 0; k < 5; k++) rsolimp[k] = G.g_solimp[k];
           }
@@ -1232,7 +1334,9 @@ __global__ __launch_bounds__(64, RPL == 1 ? 4 : 2) void env_kernel(KArgs A) {
         if (ln < NV) { D[1100 + ln] = S.qsm[ln]; for (int q = 0; q < 6; q++) D[1200 + ln * 6 + q] = S.cdof[ln][q]; }
         D[1400 + ln] = (float)rtype[0]; D[1464 + ln] = rD[0]; D[1528 + ln] = raref[0]; D[1592 + ln] = rpos_dbg; D[1656 + ln] = Jaref[0];
         if (ln < ngen) for (int d = 0; d < NV; d++) D[2048 + ln * NV + d] = S.J[ln][d];
-        if (ln < MC) { D[1720 + ln] = ln < ncon ? S.cdist[ln] : 0.f; for (int k = 0; k < 3; k++) D[1740 + ln * 3 + k] = ln < ncon ? S.cpos[ln][k] : 0.f; }
+        if (ln < MC) { D[1720 + ln] = ln < ncon ? S.cdist[ln] : 0.f; for (int k = 0; k < 3; k++) D[1740 + ln * 3 + k] = ln < ncon ? S.cpos[ln][k] : 0.f;
+                       D[1800 + ln] = ln < ncon ? (float)S.cgeom[ln] : -1.f;
+                       for (int k = 0; k < 3; k++) D[1820 + ln * 3 + k] = (NRM && ln < ncon) ? S.cnrm[NRM ? ln : 0][k] : (k == 2 ? 1.f : 0.f); }
       }
 #pragma nounroll
       while (niter < maxiter) {
@@ -1381,17 +1485,19 @@ __global__ __launch_bounds__(64, RPL == 1 ? 4 : 2) void env_kernel(KArgs A) {
         if (ln > 0 && ln < nbody && ((dm.term_bodymask >> ln) & 1u)) {
           float wr[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
           for (int c = 0; c < ncon; c++) {
-            const int g = S.cgeom[c];
-            if (dm.rec[g].g_body != ln) continue;
-            const float mu = S.p_gmu[g];
+            const int gg = S.cgeom[c], g = gg & 0xff, g1 = (gg >> 8) - 1;
+            const bool on2 = dm.rec[g].g_body == ln, on1 = SC && g1 >= 0 && dm.rec[g1 >= 0 ? g1 : 0].g_body == ln;
+            if (!on2 && !on1) continue;
+            const float mu = (SC && g1 >= 0) ? fmaxf(MINMU, fmaxf(A.gext[g].w, A.gext[g1].w)) : S.p_gmu[g];
             const float* f = &S.w.r.rowf[ne + 4 * c];
-            float nrm[3] = {HF ? S.cnrm[HF ? c : 0][0] : 0.f, HF ? S.cnrm[HF ? c : 0][1] : 0.f, HF ? S.cnrm[HF ? c : 0][2] : 1.f}, t1[3], t2[3];
+            float nrm[3] = {NRM ? S.cnrm[NRM ? c : 0][0] : 0.f, NRM ? S.cnrm[NRM ? c : 0][1] : 0.f, NRM ? S.cnrm[NRM ? c : 0][2] : 1.f}, t1[3], t2[3];
             make_frame(nrm, t1, t2);
             const float fl0 = f[0] + f[1] + f[2] + f[3], fl1 = (f[0] - f[1]) * mu, fl2 = (f[2] - f[3]) * mu;  // mj_contactForce, pyramidal
             float fw[3], dif[3], tq[3];
             for (int k = 0; k < 3; k++) { fw[k] = nrm[k] * fl0 + t1[k] * fl1 + t2[k] * fl2; dif[k] = S.cpos[c][k] - com[k]; }
             cross(tq, dif, fw);
-            for (int k = 0; k < 3; k++) { wr[k] += tq[k]; wr[3 + k] += fw[k]; }
+            const float sgn = on2 ? 1.f : -1.f;   // equal and opposite on geom1's body
+            for (int k = 0; k < 3; k++) { wr[k] += sgn * tq[k]; wr[3 + k] += sgn * fw[k]; }
           }
           for (int k = 0; k < 6; k++) hit = hit || (wr[k] > 1.0f);
         }

@@ -1541,6 +1541,14 @@ int oracle_mpr_pair(oracle_data* d, int g1, int g2, double* out7) {
   return mpr_penetration(&o1, &o2, out7, out7 + 1, out7 + 4);
 }
 void oracle_set_self_collision(oracle_data* d, int on) { d->no_self_collision = !on; }
+/* MPR between two primitives given directly (kind: CO_SPHERE/CO_CYLINDER/CO_BOX; pose = pos3 + row-major mat9; size3) */
+int oracle_mpr_prims(int k1, const double* pose1, const double* size1, int k2, const double* pose2, const double* size2, double* out7) {
+  cobj_t o1, o2;
+  memset(&o1, 0, sizeof o1); memset(&o2, 0, sizeof o2);
+  o1.kind = k1; memcpy(o1.pos, pose1, 24); memcpy(o1.mat, pose1 + 3, 72); memcpy(o1.size, size1, 24); memcpy(o1.center, pose1, 24);
+  o2.kind = k2; memcpy(o2.pos, pose2, 24); memcpy(o2.mat, pose2 + 3, 72); memcpy(o2.size, size2, 24); memcpy(o2.center, pose2, 24);
+  return mpr_penetration(&o1, &o2, out7, out7 + 1, out7 + 4);
+}
 
 /* One control step of the robot-env layer (reference flamingo_light_v1.py:131-154): PD torque from the (already
    delay-filtered) action, held over frame_skip substeps.  Returns the applied torques in tq[nu]. */

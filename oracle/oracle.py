@@ -48,6 +48,10 @@ def lib():
         L.oracle_reset.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
         L.oracle_contact.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
         L.oracle_control_step.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+        L.oracle_mpr_pair.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+        L.oracle_mpr_prims.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
+                                       ctypes.c_void_p]
+        L.oracle_set_self_collision.argtypes = [ctypes.c_void_p, ctypes.c_int]
         L.oracle_ray_down.restype = ctypes.c_double
         L.oracle_ray_down.argtypes = [ctypes.c_void_p, ctypes.c_double, ctypes.c_double, ctypes.c_double]
         _lib = L
@@ -133,10 +137,19 @@ class Oracle:
         raise AttributeError(name)
 
     def contacts(self) -> np.ndarray:
-        out = np.zeros((self.ncon, 9))
+        out = np.zeros((self.ncon, 10))   # dist, pos3, normal3, geom2, efc_address, geom1 (-1: ground)
         for i in range(self.ncon):
             self.L.oracle_contact(self.h, i, out[i].ctypes.data)
         return out
+
+    def set_self_collision(self, on: bool):
+        self.L.oracle_set_self_collision(self.h, int(on))
+
+    def mpr_pair(self, g1: int, g2: int):
+        """One MPR query between robot geoms g1, g2 at the current pose: (hit, depth, dir[3] g1->g2, pos[3])."""
+        out = np.zeros(7)
+        rc = self.L.oracle_mpr_pair(self.h, g1, g2, out.ctypes.data)
+        return rc == 0, out[0], out[1:4].copy(), out[4:7].copy()
 
     # ---- stepping
     def reset(self, qpos: Optional[np.ndarray] = None, qvel: Optional[np.ndarray] = None):
