@@ -994,7 +994,7 @@ __global__ __launch_bounds__(64, RPL == 1 ? 4 : 2) void env_kernel(KArgs A) {
               make_cobj(o1, g1);
               make_cobj(o2, g2);
               const MprPair<GTM, false> sup{o1, o2, A.hull_vert, ln};
-              hit = mpr_penetration(sup, o1.center, o2.center, depth, cn, cp) && !mpr_vzero(cn);
+              hit = mpr_penetration(sup, o1.center, o2.center, depth, cn, cp) && (cn[0] != 0.f || cn[1] != 0.f || cn[2] != 0.f);
             }
           }
           {
@@ -1018,7 +1018,7 @@ __global__ __launch_bounds__(64, RPL == 1 ? 4 : 2) void env_kernel(KArgs A) {
               make_cobj(o2, h2);
               const MprPair<GTM, true> sup{o1, o2, A.hull_vert, ln};
               float dep2 = 0.f, n2[3] = {0.f, 0.f, 1.f}, c2[3] = {0.f, 0.f, 0.f};
-              const bool hit2 = mpr_penetration(sup, o1.center, o2.center, dep2, n2, c2) && !mpr_vzero(n2);
+              const bool hit2 = mpr_penetration(sup, o1.center, o2.center, dep2, n2, c2) && (n2[0] != 0.f || n2[1] != 0.f || n2[2] != 0.f);
               if (hit2) {
                 if (ln == 0 && ncon < MC) {
                   S.cdist[ncon] = -dep2;
@@ -1335,8 +1335,8 @@ __global__ __launch_bounds__(64, RPL == 1 ? 4 : 2) void env_kernel(KArgs A) {
         D[1400 + ln] = (float)rtype[0]; D[1464 + ln] = rD[0]; D[1528 + ln] = raref[0]; D[1592 + ln] = rpos_dbg; D[1656 + ln] = Jaref[0];
         if (ln < ngen) for (int d = 0; d < NV; d++) D[2048 + ln * NV + d] = S.J[ln][d];
         if (ln < MC) { D[1720 + ln] = ln < ncon ? S.cdist[ln] : 0.f; for (int k = 0; k < 3; k++) D[1740 + ln * 3 + k] = ln < ncon ? S.cpos[ln][k] : 0.f;
-                       D[1800 + ln] = ln < ncon ? (float)S.cgeom[ln] : -1.f;
-                       for (int k = 0; k < 3; k++) D[1820 + ln * 3 + k] = (NRM && ln < ncon) ? S.cnrm[NRM ? ln : 0][k] : (k == 2 ? 1.f : 0.f); }
+                       D[1900 + ln] = ln < ncon ? (float)S.cgeom[ln] : -1.f;
+                       for (int k = 0; k < 3; k++) D[1920 + ln * 3 + k] = (NRM && ln < ncon) ? S.cnrm[NRM ? ln : 0][k] : (k == 2 ? 1.f : 0.f); }
       }
 #pragma nounroll
       while (niter < maxiter) {

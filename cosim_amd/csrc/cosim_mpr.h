@@ -1,10 +1,10 @@
-// cosim_mpr.h — convex-convex narrowphase of the rollout kernel: Minkowski Portal Refinement in fp32.
+// cosim_mpr.h — convex-convex narrowphase of the rollout kernel: Minkowski Portal Refinement (fp32 supports, fp64 portal).
 //
 // MuJoCo 3.2.7 sends every geom pair without an analytic routine (for the cosim robots: mesh / cylinder / box pairs)
 // through libccd's ccdMPRPenetration (engine_collision_convex.c mjc_Convex -> mjc_MPRIteration; libccd 2.1 src/mpr.c is a
 // third-party dependency, absent from the reference tree).  The routine below restates the published algorithm
 // (G. Snethen, "XenoCollide", Game Programming Gems 7) with libccd's structure -- discoverPortal, refinePortal,
-// findPenetr, findPos -- and its predicates, with FLT_EPSILON in place of DBL_EPSILON, mpr_tolerance 1e-6 and at most
+// findPenetr, findPos -- and its predicates, portal arithmetic in fp64 on fp32 support points, mpr_tolerance 1e-6 and at most
 // 50 iterations per loop (MuJoCo's ccd_tolerance / ccd_iterations; libccd's refinePortal is uncapped, here every loop is
 // bounded so that every wave reaches the end of the kernel).  oracle/cosim_oracle.c holds the fp64 twin.
 //
@@ -16,8 +16,8 @@
 
 namespace cosim {
 
-constexpr float MPR_EPS = 1.1920929e-07f;
-constexpr float MPR_TOL = 1e-6f;
+constexpr double MPR_EPS = 2.220446049250313e-16;
+constexpr double MPR_TOL = 1e-6;
 constexpr int MPR_MAXIT = 50;
 
 struct CObj {            // one convex geom, world pose
@@ -27,21 +27,26 @@ struct CObj {            // one convex geom, world pose
   int adr, num;          // mesh: slice of the hull vertex array
   float center[3];       // mjccd_center
 };
-struct MprSup { float v[3], v1[3]; };  // Minkowski-difference support point v = s1(dir) - s2(-dir) and its s1 part
+typedef double real;   // the portal arithmetic runs in fp64 (ill-conditioned for edge contacts); supports are fp32
+__device__ __forceinline__ real mpr_dot(const real* a, const real* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+__device__ __forceinline__ void mpr_cross(real* r, const real* a, const real* b) {
+  r[0] = a[1] * b[2] - a[2] * b[1]; r[1] = a[2] * b[0] - a[0] * b[2]; r[2] = a[0] * b[1] - a[1] * b[0];
+}
+struct MprSup { real v[3], v1[3]; };  // Minkowski-difference support point v = s1(dir) - s2(-dir) and its s1 part
 
-__device__ __forceinline__ bool mpr_zero(float x) { return fabsf(x) < MPR_EPS; }
-__device__ __forceinline__ bool mpr_eq(float a, float b) {
-  const float ab = fabsf(a - b);
+__device__ __forceinline__ bool mpr_zero(real x) { return fabs(x) < MPR_EPS; }
+__device__ __forceinline__ bool mpr_eq(real a, real b) {
+  const real ab = fabs(a - b);
   if (ab < MPR_EPS) return true;
-  a = fabsf(a); b = fabsf(b);
+  a = fabs(a); b = fabs(b);
   return b > a ? ab < MPR_EPS * b : ab < MPR_EPS * a;
 }
-__device__ __forceinline__ bool mpr_vzero(const float* v) { return mpr_eq(v[0], 0.f) && mpr_eq(v[1], 0.f) && mpr_eq(v[2], 0.f); }
+__device__ __forceinline__ bool mpr_vzero(const real* v) { return mpr_eq(v[0], 0.) && mpr_eq(v[1], 0.) && mpr_eq(v[2], 0.); }
 __device__ __forceinline__ float mpr_sign(float x) { return x > 0.f ? 1.f : (x < 0.f ? -1.f : 0.f); }   // mju_sign
-__device__ __forceinline__ float mpr_normalize(float* v) {
-  const float n = sqrtf(dot3(v, v));
-  if (n < 1e-30f) { v[0] = 1.f; v[1] = 0.f; v[2] = 0.f; return 0.f; }
-  const float s = 1.f / n;
+__device__ __forceinline__ real mpr_normalize(real* v) {
+  const real n = sqrt(mpr_dot(v, v));
+  if (n < 1e-300) { v[0] = 1.; v[1] = 0.; v[2] = 0.; return 0.; }
+  const real s = 1. / n;
   v[0] *= s; v[1] *= s; v[2] *= s;
   return n;
 }
@@ -86,56 +91,56 @@ struct MprPair {
   const CObj &a, &b;
   const float* hull;
   int ln;
-  __device__ __forceinline__ void operator()(const float* dir, MprSup& s) const {   // __ccdSupport
-    const float nd[3] = {-dir[0], -dir[1], -dir[2]};
-    float v2[3];
-    cobj_support<GTM, COOP>(a, hull, dir, s.v1, ln);
+  __device__ __forceinline__ void operator()(const real* dir, MprSup& s) const {   // __ccdSupport
+    const float fd[3] = {(float)dir[0], (float)dir[1], (float)dir[2]}, nd[3] = {-fd[0], -fd[1], -fd[2]};
+    float v1[3], v2[3];
+    cobj_support<GTM, COOP>(a, hull, fd, v1, ln);
     cobj_support<GTM, COOP>(b, hull, nd, v2, ln);
-    s.v[0] = s.v1[0] - v2[0]; s.v[1] = s.v1[1] - v2[1]; s.v[2] = s.v1[2] - v2[2];
+    for (int k = 0; k < 3; k++) { s.v1[k] = (real)v1[k]; s.v[k] = (real)v1[k] - (real)v2[k]; }
   }
 };
 
-__device__ __forceinline__ void mpr_portal_dir(const MprSup& p1, const MprSup& p2, const MprSup& p3, float* dir) {
-  const float a[3] = {p2.v[0] - p1.v[0], p2.v[1] - p1.v[1], p2.v[2] - p1.v[2]}, b[3] = {p3.v[0] - p1.v[0], p3.v[1] - p1.v[1], p3.v[2] - p1.v[2]};
-  cross(dir, a, b);
+__device__ __forceinline__ void mpr_portal_dir(const MprSup& p1, const MprSup& p2, const MprSup& p3, real* dir) {
+  const real a[3] = {p2.v[0] - p1.v[0], p2.v[1] - p1.v[1], p2.v[2] - p1.v[2]}, b[3] = {p3.v[0] - p1.v[0], p3.v[1] - p1.v[1], p3.v[2] - p1.v[2]};
+  mpr_cross(dir, a, b);
   mpr_normalize(dir);
 }
-__device__ __forceinline__ bool mpr_reach_tol(const MprSup& p1, const MprSup& p2, const MprSup& p3, const MprSup& v4, const float* dir) {
-  const float dv4 = dot3(v4.v, dir);
-  const float d = fminf(dv4 - dot3(p1.v, dir), fminf(dv4 - dot3(p2.v, dir), dv4 - dot3(p3.v, dir)));
+__device__ __forceinline__ bool mpr_reach_tol(const MprSup& p1, const MprSup& p2, const MprSup& p3, const MprSup& v4, const real* dir) {
+  const real dv4 = mpr_dot(v4.v, dir);
+  const real d = fmin(dv4 - mpr_dot(p1.v, dir), fmin(dv4 - mpr_dot(p2.v, dir), dv4 - mpr_dot(p3.v, dir)));
   return mpr_eq(d, MPR_TOL) || d < MPR_TOL;
 }
-__device__ __forceinline__ void mpr_expand(const float* v0, MprSup& p1, MprSup& p2, MprSup& p3, const MprSup& v4) {
-  float v4v0[3];
-  cross(v4v0, v4.v, v0);
-  if (dot3(p1.v, v4v0) > 0.f) {
-    if (dot3(p2.v, v4v0) > 0.f) p1 = v4; else p3 = v4;
+__device__ __forceinline__ void mpr_expand(const real* v0, MprSup& p1, MprSup& p2, MprSup& p3, const MprSup& v4) {
+  real v4v0[3];
+  mpr_cross(v4v0, v4.v, v0);
+  if (mpr_dot(p1.v, v4v0) > 0.) {
+    if (mpr_dot(p2.v, v4v0) > 0.) p1 = v4; else p3 = v4;
   } else {
-    if (dot3(p3.v, v4v0) > 0.f) p2 = v4; else p1 = v4;
+    if (mpr_dot(p3.v, v4v0) > 0.) p2 = v4; else p1 = v4;
   }
 }
-__device__ __forceinline__ float mpr_seg_dist2(const float* x0, const float* b, float* wit) {   // ccdVec3PointSegmentDist2, P = origin
-  const float d[3] = {b[0] - x0[0], b[1] - x0[1], b[2] - x0[2]};
-  const float dd = dot3(d, d);
-  const float t = dd > 0.f ? -dot3(x0, d) / dd : 0.f;
-  if (t < 0.f || mpr_zero(t)) { wit[0] = x0[0]; wit[1] = x0[1]; wit[2] = x0[2]; return dot3(x0, x0); }
-  if (t > 1.f || mpr_eq(t, 1.f)) { wit[0] = b[0]; wit[1] = b[1]; wit[2] = b[2]; return dot3(b, b); }
+__device__ __forceinline__ real mpr_seg_dist2(const real* x0, const real* b, real* wit) {   // ccdVec3PointSegmentDist2, P = origin
+  const real d[3] = {b[0] - x0[0], b[1] - x0[1], b[2] - x0[2]};
+  const real dd = mpr_dot(d, d);
+  const real t = dd > 0. ? -mpr_dot(x0, d) / dd : 0.;
+  if (t < 0. || mpr_zero(t)) { wit[0] = x0[0]; wit[1] = x0[1]; wit[2] = x0[2]; return mpr_dot(x0, x0); }
+  if (t > 1. || mpr_eq(t, 1.)) { wit[0] = b[0]; wit[1] = b[1]; wit[2] = b[2]; return mpr_dot(b, b); }
   wit[0] = x0[0] + t * d[0]; wit[1] = x0[1] + t * d[1]; wit[2] = x0[2] + t * d[2];
-  return dot3(wit, wit);
+  return mpr_dot(wit, wit);
 }
-__device__ __forceinline__ float mpr_tri_dist2(const float* x0, const float* B, const float* C, float* wit) {   // ccdVec3PointTriDist2, P = origin
-  const float d1[3] = {B[0] - x0[0], B[1] - x0[1], B[2] - x0[2]}, d2[3] = {C[0] - x0[0], C[1] - x0[1], C[2] - x0[2]};
-  const float v = dot3(d1, d1), w = dot3(d2, d2), p = dot3(x0, d1), q = dot3(x0, d2), r = dot3(d1, d2);
-  const float den = w * v - r * r;
-  const float s = (q * r - w * p) / den, t = (-s * r - q) / w;   // degenerate triangle: NaN fails every test below
-  if ((mpr_zero(s) || s > 0.f) && (mpr_eq(s, 1.f) || s < 1.f) && (mpr_zero(t) || t > 0.f) && (mpr_eq(t, 1.f) || t < 1.f) &&
-      (mpr_eq(t + s, 1.f) || t + s < 1.f)) {
+__device__ __forceinline__ real mpr_tri_dist2(const real* x0, const real* B, const real* C, real* wit) {   // ccdVec3PointTriDist2, P = origin
+  const real d1[3] = {B[0] - x0[0], B[1] - x0[1], B[2] - x0[2]}, d2[3] = {C[0] - x0[0], C[1] - x0[1], C[2] - x0[2]};
+  const real v = mpr_dot(d1, d1), w = mpr_dot(d2, d2), p = mpr_dot(x0, d1), q = mpr_dot(x0, d2), r = mpr_dot(d1, d2);
+  const real den = w * v - r * r;
+  const real s = (q * r - w * p) / den, t = (-s * r - q) / w;   // degenerate triangle: NaN fails every test below
+  if ((mpr_zero(s) || s > 0.) && (mpr_eq(s, 1.) || s < 1.) && (mpr_zero(t) || t > 0.) && (mpr_eq(t, 1.) || t < 1.) &&
+      (mpr_eq(t + s, 1.) || t + s < 1.)) {
     wit[0] = x0[0] + s * d1[0] + t * d2[0]; wit[1] = x0[1] + s * d1[1] + t * d2[1]; wit[2] = x0[2] + s * d1[2] + t * d2[2];
-    return dot3(wit, wit);
+    return mpr_dot(wit, wit);
   }
-  float w2[3];
-  float dist = mpr_seg_dist2(x0, B, wit);
-  float dist2 = mpr_seg_dist2(x0, C, w2);
+  real w2[3];
+  real dist = mpr_seg_dist2(x0, B, wit);
+  real dist2 = mpr_seg_dist2(x0, C, w2);
   if (dist2 < dist) { dist = dist2; wit[0] = w2[0]; wit[1] = w2[1]; wit[2] = w2[2]; }
   dist2 = mpr_seg_dist2(B, C, w2);
   if (dist2 < dist) { dist = dist2; wit[0] = w2[0]; wit[1] = w2[1]; wit[2] = w2[2]; }
@@ -144,34 +149,37 @@ __device__ __forceinline__ float mpr_tri_dist2(const float* x0, const float* B, 
 
 // ccdMPRPenetration: true when the geoms penetrate; depth, dir (geom1 -> geom2) and pos as libccd returns them.
 template <class SUP>
-__device__ __forceinline__ bool mpr_penetration(const SUP& sup, const float* c1, const float* c2, float& depth, float* dir_out, float* pos) {
+__device__ __forceinline__ bool mpr_penetration(const SUP& sup, const float* c1, const float* c2, float& depth_out, float* dir_f, float* pos_f) {
   MprSup p1, p2, p3, v4;
-  float v0[3] = {c1[0] - c2[0], c1[1] - c2[1], c1[2] - c2[2]};
-  float dir[3], va[3], vb[3], dt;
+  real depth, dir_out[3], pos[3];
+  real v0[3] = {(real)c1[0] - (real)c2[0], (real)c1[1] - (real)c2[1], (real)c1[2] - (real)c2[2]};
+  real dir[3], va[3], vb[3], dt;
   // ---- discoverPortal
-  if (mpr_vzero(v0)) v0[0] += MPR_EPS * 10.f;
+  if (mpr_vzero(v0)) v0[0] += MPR_EPS * 10.;
   dir[0] = -v0[0]; dir[1] = -v0[1]; dir[2] = -v0[2];
   mpr_normalize(dir);
   sup(dir, p1);
-  dt = dot3(p1.v, dir);
-  if (mpr_zero(dt) || dt < 0.f) return false;
-  cross(dir, v0, p1.v);
-  if (mpr_zero(dot3(dir, dir))) {
+  dt = mpr_dot(p1.v, dir);
+  if (mpr_zero(dt) || dt < 0.) return false;
+  mpr_cross(dir, v0, p1.v);
+  if (mpr_zero(mpr_dot(dir, dir))) {
     if (mpr_vzero(p1.v)) return false;                    // touching: depth 0, no direction -> MuJoCo drops it
     // origin on the v0-v1 segment (findPenetrSegment): v2 of the support = v1 - v
-    pos[0] = p1.v1[0] - 0.5f * p1.v[0]; pos[1] = p1.v1[1] - 0.5f * p1.v[1]; pos[2] = p1.v1[2] - 0.5f * p1.v[2];
+    pos[0] = p1.v1[0] - 0.5 * p1.v[0]; pos[1] = p1.v1[1] - 0.5 * p1.v[1]; pos[2] = p1.v1[2] - 0.5 * p1.v[2];
     dir_out[0] = p1.v[0]; dir_out[1] = p1.v[1]; dir_out[2] = p1.v[2];
     depth = mpr_normalize(dir_out);
-    return depth > 0.f;
+    depth_out = (float)depth;
+    for (int k = 0; k < 3; k++) { dir_f[k] = (float)dir_out[k]; pos_f[k] = (float)pos[k]; }
+    return depth > 0.;
   }
   mpr_normalize(dir);
   sup(dir, p2);
-  dt = dot3(p2.v, dir);
-  if (mpr_zero(dt) || dt < 0.f) return false;
+  dt = mpr_dot(p2.v, dir);
+  if (mpr_zero(dt) || dt < 0.) return false;
   for (int k = 0; k < 3; k++) { va[k] = p1.v[k] - v0[k]; vb[k] = p2.v[k] - v0[k]; }
-  cross(dir, va, vb);
+  mpr_cross(dir, va, vb);
   mpr_normalize(dir);
-  if (dot3(dir, v0) > 0.f) {
+  if (mpr_dot(dir, v0) > 0.) {
     const MprSup t = p1; p1 = p2; p2 = t;
     dir[0] = -dir[0]; dir[1] = -dir[1]; dir[2] = -dir[2];
   }
@@ -180,20 +188,20 @@ __device__ __forceinline__ bool mpr_penetration(const SUP& sup, const float* c1,
     for (;;) {
       if (++it > MPR_MAXIT) return false;
       sup(dir, p3);
-      dt = dot3(p3.v, dir);
-      if (mpr_zero(dt) || dt < 0.f) return false;
+      dt = mpr_dot(p3.v, dir);
+      if (mpr_zero(dt) || dt < 0.) return false;
       bool cont = false;
-      cross(va, p1.v, p3.v);
-      dt = dot3(va, v0);
-      if (dt < 0.f && !mpr_zero(dt)) { p2 = p3; cont = true; }
+      mpr_cross(va, p1.v, p3.v);
+      dt = mpr_dot(va, v0);
+      if (dt < 0. && !mpr_zero(dt)) { p2 = p3; cont = true; }
       if (!cont) {
-        cross(va, p3.v, p2.v);
-        dt = dot3(va, v0);
-        if (dt < 0.f && !mpr_zero(dt)) { p1 = p3; cont = true; }
+        mpr_cross(va, p3.v, p2.v);
+        dt = mpr_dot(va, v0);
+        if (dt < 0. && !mpr_zero(dt)) { p1 = p3; cont = true; }
       }
       if (!cont) break;
       for (int k = 0; k < 3; k++) { va[k] = p1.v[k] - v0[k]; vb[k] = p2.v[k] - v0[k]; }
-      cross(dir, va, vb);
+      mpr_cross(dir, va, vb);
       mpr_normalize(dir);
     }
   }
@@ -203,11 +211,11 @@ __device__ __forceinline__ bool mpr_penetration(const SUP& sup, const float* c1,
     for (;;) {
       if (++it > MPR_MAXIT) return false;
       mpr_portal_dir(p1, p2, p3, dir);
-      dt = dot3(dir, p1.v);
-      if (mpr_zero(dt) || dt > 0.f) break;               // portalEncapsulesOrigin
+      dt = mpr_dot(dir, p1.v);
+      if (mpr_zero(dt) || dt > 0.) break;               // portalEncapsulesOrigin
       sup(dir, v4);
-      dt = dot3(v4.v, dir);
-      if (!(mpr_zero(dt) || dt > 0.f) || mpr_reach_tol(p1, p2, p3, v4, dir)) return false;
+      dt = mpr_dot(v4.v, dir);
+      if (!(mpr_zero(dt) || dt > 0.) || mpr_reach_tol(p1, p2, p3, v4, dir)) return false;
       mpr_expand(v0, p1, p2, p3, v4);
     }
   }
@@ -222,35 +230,37 @@ __device__ __forceinline__ bool mpr_penetration(const SUP& sup, const float* c1,
       it++;
     }
   }
-  float pd[3];
-  depth = sqrtf(mpr_tri_dist2(p1.v, p2.v, p3.v, pd));
+  real pd[3];
+  depth = sqrt(mpr_tri_dist2(p1.v, p2.v, p3.v, pd));
   if (mpr_zero(pd[0]) && mpr_zero(pd[1]) && mpr_zero(pd[2])) { pd[0] = dir[0]; pd[1] = dir[1]; pd[2] = dir[2]; }
   mpr_normalize(pd);
   dir_out[0] = pd[0]; dir_out[1] = pd[1]; dir_out[2] = pd[2];
   // ---- findPos: barycentric coordinates of the origin in the portal tetrahedron
   {
-    float b0, b1, b2, b3, vec[3];
+    real b0, b1, b2, b3, vec[3];
     mpr_portal_dir(p1, p2, p3, dir);
-    cross(vec, p1.v, p2.v); b0 = dot3(vec, p3.v);
-    cross(vec, p3.v, p2.v); b1 = dot3(vec, v0);
-    cross(vec, v0, p1.v);   b2 = dot3(vec, p3.v);
-    cross(vec, p2.v, p1.v); b3 = dot3(vec, v0);
-    float sum = b0 + b1 + b2 + b3;
-    if (mpr_zero(sum) || sum < 0.f) {
-      b0 = 0.f;
-      cross(vec, p2.v, p3.v); b1 = dot3(vec, dir);
-      cross(vec, p3.v, p1.v); b2 = dot3(vec, dir);
-      cross(vec, p1.v, p2.v); b3 = dot3(vec, dir);
+    mpr_cross(vec, p1.v, p2.v); b0 = mpr_dot(vec, p3.v);
+    mpr_cross(vec, p3.v, p2.v); b1 = mpr_dot(vec, v0);
+    mpr_cross(vec, v0, p1.v);   b2 = mpr_dot(vec, p3.v);
+    mpr_cross(vec, p2.v, p1.v); b3 = mpr_dot(vec, v0);
+    real sum = b0 + b1 + b2 + b3;
+    if (mpr_zero(sum) || sum < 0.) {
+      b0 = 0.;
+      mpr_cross(vec, p2.v, p3.v); b1 = mpr_dot(vec, dir);
+      mpr_cross(vec, p3.v, p1.v); b2 = mpr_dot(vec, dir);
+      mpr_cross(vec, p1.v, p2.v); b3 = mpr_dot(vec, dir);
       sum = b1 + b2 + b3;
     }
-    const float inv = 1.f / sum;
+    const real inv = 1. / sum;
     for (int k = 0; k < 3; k++) {
       // p1' = sum b_i v1_i, p2' = sum b_i v2_i with v2_i = v1_i - v_i;  pos = (p1' + p2') / 2
-      const float s1 = b0 * c1[k] + b1 * p1.v1[k] + b2 * p2.v1[k] + b3 * p3.v1[k];
-      const float sv = b0 * v0[k] + b1 * p1.v[k] + b2 * p2.v[k] + b3 * p3.v[k];
-      pos[k] = (s1 - 0.5f * sv) * inv;
+      const real s1 = b0 * (real)c1[k] + b1 * p1.v1[k] + b2 * p2.v1[k] + b3 * p3.v1[k];
+      const real sv = b0 * v0[k] + b1 * p1.v[k] + b2 * p2.v[k] + b3 * p3.v[k];
+      pos[k] = (s1 - 0.5 * sv) * inv;
     }
   }
+  depth_out = (float)depth;
+  for (int k = 0; k < 3; k++) { dir_f[k] = (float)dir_out[k]; pos_f[k] = (float)pos[k]; }
   return isfinite(depth) && isfinite(pos[0]) && isfinite(pos[1]) && isfinite(pos[2]);
 }
 

@@ -293,7 +293,7 @@ def test_single_env_adapter_keeps_reference_api(parity):
 def test_other_robots_one_control_step_replay_flat(env_id, steps):
     """The other three robots on flat ground (nv 14 / 22 / 29; two constraint rows per lane, geared legs, box and
     cylinder and convex-hull feet / wheels, free-joint armature + frictionloss): one-control-step replay of states
-    along an oracle trajectory.  Robot self-collision pairs are compiled but not collided by either side."""
+    along an oracle trajectory (robot-robot pairs included: see test_self_collision_mpr_matches_oracle)."""
     import torch
     from cosim_amd.batched_env import BatchedEnv
     from cosim_amd.compile import compile_model
@@ -474,4 +474,72 @@ def test_position_command_masked_reset_and_push_on_device(parity):
     for e in (0, 2):
         np.testing.assert_allclose(qv[e, 0:3], push_velocity(qp[e], v), atol=1e-6)
     assert np.abs(qv[1, 0:3]).max() == 0.0
+    env.close()
+
+
+@pytest.mark.parametrize("env_id,steps,amp", [("humanoid_p_v0", 400, 0.6), ("flamingo_p_v3", 300, 0.9), ("w4_p_v2", 300, 0.9)])
+def test_self_collision_mpr_matches_oracle(env_id, steps, amp):
+    """Robot-robot pairs (body-body for the 1/1 masks): the fp32-support / fp64-portal MPR of the HIP engine
+    against the oracle's fp64 MPR on every state of a falling-robot trajectory that has a self contact, plus the
+    one-control-step replay through those states (two-body contact Jacobians, mixed friction)."""
+    import torch
+    from cosim_amd.batched_env import BatchedEnv
+    from cosim_amd.compile import compile_model
+    from cosim_amd.config import PARITY_RANDOM, make_config
+    from cosim_amd.model import get_field
+    from oracle.oracle import Oracle
+    cfg = make_config(env_id, random=PARITY_RANDOM)
+    cm = compile_model(cfg)
+    b = cm.blob
+    o = Oracle(cm)
+    o.reset(np.array(get_field(b, "init_qpos")[:b.nq]))
+    phi = np.random.default_rng(0).uniform(0, 6.28, b.nu)
+    R = dict(qpos=[], qvel=[], warm=[], act=[], qpos1=[], qvel1=[], nefc=[], nself=[])
+    for t in range(steps):
+        a = np.clip(amp * np.sin(2 * np.pi * 0.5 * t * 0.02 + phi), -1, 1)
+        R["qpos"].append(o.qpos.copy()); R["qvel"].append(o.qvel.copy()); R["warm"].append(o.qacc_warmstart.copy()); R["act"].append(a)
+        o.control_step(a)
+        c = o.contacts()
+        R["nself"].append(int((c[:, 9] >= 0).sum()) if len(c) else 0)
+        R["qpos1"].append(o.qpos.copy()); R["qvel1"].append(o.qvel.copy()); R["nefc"].append(o.nefc)
+        assert not o.bad
+    R = {k: np.array(v) for k, v in R.items()}
+    sc = R["nself"] > 0
+    assert sc.sum() >= 20                                          # the trajectory does exercise self contacts
+    env = BatchedEnv(cfg, num_envs=steps, auto_reset=False, compiled=cm)
+    env.reset()
+    env.set_state(R["qpos"], R["qvel"], R["warm"])
+    # --- narrowphase parity, contact by contact
+    nmatch, good, miss = 0, 0, 0
+    for w in range(steps):
+        o.reset(R["qpos"][w], R["qvel"][w])
+        o.forward()
+        oc = o.contacts()
+        if not len(oc) or not (oc[:, 9] >= 0).any():
+            continue
+        dbg = env.engine.debug_forward(int(w))
+        gpu = {}
+        for i in range(min(int(dbg[0]), 16)):
+            gg = int(dbg[1900 + i])
+            if (gg >> 8) - 1 >= 0:
+                gpu[((gg >> 8) - 1, gg & 255)] = (dbg[1720 + i], dbg[1740 + 3 * i:1743 + 3 * i].copy(), dbg[1920 + 3 * i:1923 + 3 * i].copy())
+        base = R["qpos"][w][:3].copy(); base[2] = 0.0              # the engine works in a base-relative frame
+        for c in oc[oc[:, 9] >= 0]:
+            key = (int(c[9]), int(c[7]))
+            if key not in gpu:
+                miss += c[0] < -1e-5                               # grazing contacts may flip
+                continue
+            nmatch += 1
+            gd, gp, gn = gpu[key]
+            good += abs(gd - c[0]) < 1e-5 and np.abs(gn - c[4:7]).max() < 1e-3 and np.abs(gp + base - c[1:4]).max() < 1e-4
+    assert miss == 0 and nmatch >= 20
+    # ill-conditioned edge contacts: the final portal can differ between fp32 and fp64 poses; they must stay rare
+    assert good >= 0.95 * nmatch, (good, nmatch)
+    # --- one-control-step replay through the same states
+    env.step(torch.tensor(R["act"], dtype=torch.float32, device=env.device))
+    d = env.get_data()
+    qv = d.qvel.cpu().numpy().astype(np.float64)
+    ev = np.abs(qv - R["qvel1"]).max(axis=1)
+    ok = (R["nefc"] <= 110) & sc
+    assert np.median(ev[ok]) < 2e-4 and np.quantile(ev[ok], 0.9) < 5e-3, (np.median(ev[ok]), np.quantile(ev[ok], 0.9))
     env.close()

@@ -196,3 +196,73 @@ def test_newton_solution_is_the_minimiser(cm):
     for _ in range(50):
         d = rng.normal(size=cm.blob.nv) * 10 ** rng.uniform(-4, 0)
         assert cost(o.qacc + d) >= c0 - 1e-9 * max(1.0, abs(c0))
+
+
+def test_mpr_known_answers_on_primitives():
+    """libccd-style MPR restatement (oracle/cosim_oracle.c mpr_penetration) on pairs with closed-form answers."""
+    import ctypes
+    from oracle.oracle import lib
+    L = lib()
+
+    def q(k1, p1, R1, s1, k2, p2, R2, s2):
+        a = np.concatenate([p1, np.asarray(R1).ravel()]).astype(np.float64)
+        b = np.concatenate([p2, np.asarray(R2).ravel()]).astype(np.float64)
+        s1 = np.asarray(s1, dtype=np.float64); s2 = np.asarray(s2, dtype=np.float64)
+        out = np.zeros(7)
+        rc = L.oracle_mpr_prims(k1, a.ctypes.data, s1.ctypes.data, k2, b.ctypes.data, s2.ctypes.data, out.ctypes.data)
+        return rc, out[0], out[1:4], out[4:7]
+    I = np.eye(3)
+    SPH, CYL, BOX = 0, 1, 2
+    # two spheres: depth = r1 + r2 - |c|, normal along the centre line, position midway through the overlap
+    c = np.array([0.6, 0.5, 0.3])
+    rc, depth, n, pos = q(SPH, [0, 0, 0], I, [0.5, 0, 0], SPH, c, I, [0.5, 0, 0])
+    assert rc == 0 and depth == pytest.approx(1 - np.linalg.norm(c), abs=1e-6)
+    np.testing.assert_allclose(n, c / np.linalg.norm(c), atol=1e-4)
+    np.testing.assert_allclose(pos, 0.5 * c, atol=1e-4)
+    # axis-aligned boxes overlapping 0.1 along x
+    rc, depth, n, pos = q(BOX, [0, 0, 0], I, [0.5, 0.5, 0.5], BOX, [0.9, 0.1, 0.05], I, [0.5, 0.5, 0.5])
+    assert rc == 0 and depth == pytest.approx(0.1, abs=1e-9)
+    np.testing.assert_allclose(n, [1, 0, 0], atol=1e-9)
+    assert pos[0] == pytest.approx(0.45, abs=1e-9)
+    # separated boxes -> no contact
+    assert q(BOX, [0, 0, 0], I, [0.5, 0.5, 0.5], BOX, [1.1, 0, 0], I, [0.5, 0.5, 0.5])[0] == -1
+    # crossed cylinders (axes z and y), centres 0.55 apart along x with radii 0.3: depth 0.05 along x
+    Rx = np.array([[1, 0, 0], [0, 0, -1], [0, 1, 0]], dtype=float)
+    rc, depth, n, pos = q(CYL, [0, 0, 0], I, [0.3, 0.5, 0], CYL, [0.55, 0, 0], Rx, [0.3, 0.5, 0])
+    assert rc == 0 and depth == pytest.approx(0.05, abs=1e-5)
+    np.testing.assert_allclose(n, [1, 0, 0], atol=1e-3)
+    np.testing.assert_allclose(pos, [0.275, 0, 0], atol=1e-3)
+
+
+def test_self_collision_forces_are_internal():
+    """Robot-robot contacts act equal and opposite on the two bodies (mj_jacDifPair / mj_rnePostConstraint): summed over
+    the bodies, cfrc_ext holds only the ground reaction, and switching the pairs off changes the motion."""
+    from cosim_amd.compile import compile_model
+    from cosim_amd.config import PARITY_RANDOM, make_config
+    from cosim_amd.model import get_field
+    from oracle.oracle import Oracle
+    cm = compile_model(make_config("humanoid_p_v0", random=PARITY_RANDOM))
+    b = cm.blob
+    o = Oracle(cm)
+    o.reset(np.array(get_field(b, "init_qpos")[:b.nq]))
+    phi = np.random.default_rng(0).uniform(0, 6.28, b.nu)
+    seen = 0
+    for t in range(300):
+        o.control_step(np.clip(0.6 * np.sin(2 * np.pi * 0.5 * t * 0.02 + phi), -1, 1))
+        c = o.contacts()
+        if len(c) and (c[:, 9] >= 0).any() and (c[:, 8] >= 0).all():
+            seen += 1
+            f = o.efc_force
+            ground = np.zeros(3)
+            for ci in c[c[:, 9] < 0]:
+                adr = int(ci[8])
+                ground += ci[4:7] * f[adr:adr + 4].sum()          # normal part of the pyramid force; tangents cancel in z only
+            total = o.cfrc_ext[:b.nbody, 3:6].sum(axis=0)
+            assert total[2] == pytest.approx(ground[2], rel=1e-9, abs=1e-9)   # ground normal is +z on the plane
+    assert seen >= 10 and not o.bad
+    z_with = o.qpos.copy()
+    o.reset(np.array(get_field(b, "init_qpos")[:b.nq]))
+    o.set_self_collision(False)
+    for t in range(300):
+        o.control_step(np.clip(0.6 * np.sin(2 * np.pi * 0.5 * t * 0.02 + phi), -1, 1))
+    assert np.abs(o.qpos - z_with).max() > 1e-3

@@ -50,22 +50,37 @@ def run(env_id, steps, amp, seed=0):
     for name, m in (("no self contact", ok & ~sc), ("self contact", ok & sc)):
         if m.sum():
             print(f"   {name:16s} n={m.sum():4d}  |dqvel| median {np.median(ev[m]):.2e} p90 {np.quantile(ev[m], 0.9):.2e} max {ev[m].max():.2e}   |dqpos| max {ep[m].max():.2e}")
-    # contact-level comparison on the worst self-contact state
-    if sc.sum():
-        idx = np.nonzero(ok & sc)[0]
-        w = idx[np.argmax(ev[idx])]
+    # contact-level comparison (MPR parity) on every state that starts with a self contact in the oracle
+    env.set_state(R["qpos"], R["qvel"], R["warm"])
+    worst = dict(dist=0.0, nrm=0.0, pos=0.0)
+    nmatch = nmiss = 0
+    for w in range(n):
         o.reset(R["qpos"][w], R["qvel"][w])
         o.forward()
         oc = o.contacts()
-        env.set_state(R["qpos"], R["qvel"], R["warm"])
+        if not len(oc) or not (oc[:, 9] >= 0).any():
+            continue
         dbg = env.engine.debug_forward(int(w))
-        nc = int(dbg[0])
-        print(f"   worst self-contact state {w}: oracle ncon {len(oc)} gpu ncon {nc}")
-        for i in range(len(oc)):
-            print("     oracle", f"g1 {int(oc[i,9]):3d} g2 {int(oc[i,7]):3d} dist {oc[i,0]: .5f} pos", np.round(oc[i, 1:4], 4), "n", np.round(oc[i, 4:7], 3))
-        for i in range(min(nc, 16)):
-            gg = int(dbg[1800 + i])
-            print("     gpu   ", f"g1 {(gg >> 8) - 1:3d} g2 {gg & 255:3d} dist {dbg[1720+i]: .5f} pos", np.round(dbg[1740 + 3 * i:1743 + 3 * i], 4), "n", np.round(dbg[1820 + 3 * i:1823 + 3 * i], 3))
+        nc = min(int(dbg[0]), 16)
+        gpu = {}
+        for i in range(nc):
+            gg = int(dbg[1900 + i])
+            if (gg >> 8) - 1 >= 0:
+                gpu[((gg >> 8) - 1, gg & 255)] = (dbg[1720 + i], dbg[1740 + 3 * i:1743 + 3 * i].copy(), dbg[1920 + 3 * i:1923 + 3 * i].copy())
+        base = R["qpos"][w][:3].copy(); base[2] = 0.0           # the engine works in a base-relative frame
+        for c in oc[oc[:, 9] >= 0]:
+            key = (int(c[9]), int(c[7]))
+            if key not in gpu:
+                nmiss += 1
+                print(f"   state {w}: pair {key} dist {c[0]:.2e} missing on the GPU (gpu self pairs: {list(gpu)})")
+                continue
+            nmatch += 1
+            gd, gp, gn = gpu[key]
+            ed, en, ep = abs(gd - c[0]), np.abs(gn - c[4:7]).max(), np.abs(gp + base - c[1:4]).max()
+            if max(ed, en * 1e-2, ep * 1e-1) > 1e-4:
+                print(f"   state {w} pair {key}: dist {c[0]:.5f}/{gd:.5f} n {np.round(c[4:7],3)}/{np.round(gn,3)} pos {np.round(c[1:4]-base,4)}/{np.round(gp,4)}")
+            worst["dist"] = max(worst["dist"], ed); worst["nrm"] = max(worst["nrm"], en); worst["pos"] = max(worst["pos"], ep)
+    print(f"   MPR contacts matched {nmatch}, missing {nmiss}; max |d dist| {worst['dist']:.2e} |d normal| {worst['nrm']:.2e} |d pos| {worst['pos']:.2e}")
     env.close()
 
 
