@@ -982,8 +982,30 @@ __global__ __launch_bounds__(64, RPL == 1 ? 4 : 2) void env_kernel(KArgs A) {
             qrot(v2, q2, G2.g_rcenter);
             float d2 = 0.f;
             for (int k = 0; k < 3; k++) { const float dk = (S.xpos[G2.g_body][k] + v2[k]) - (S.xpos[G1.g_body][k] + v1[k]); d2 += dk * dk; }
-            const float rs = G1.g_rbound + G2.g_rbound + fmaxf(G1.g_margin, G2.g_margin);
+            const float mg = fmaxf(G1.g_margin, G2.g_margin), rs = G1.g_rbound + G2.g_rbound + mg;
             cand = d2 <= rs * rs;
+            if (cand) {
+              // oriented boxes (body-frame box around each geom): centre line and the six face normals as separating axes
+              float m1[9], m2[9], dv[3];
+              q2m(m1, q1);
+              q2m(m2, q2);
+              for (int k = 0; k < 3; k++) dv[k] = (S.xpos[G2.g_body][k] + v2[k]) - (S.xpos[G1.g_body][k] + v1[k]);
+              auto radius = [](const float* m, const float* hf, const float* a) {
+                return hf[0] * fabsf(m[0] * a[0] + m[3] * a[1] + m[6] * a[2]) + hf[1] * fabsf(m[1] * a[0] + m[4] * a[1] + m[7] * a[2]) +
+                       hf[2] * fabsf(m[2] * a[0] + m[5] * a[1] + m[8] * a[2]);
+              };
+              const float dn = sqrtf(d2);
+              if (dn > 1e-9f) {
+                const float a[3] = {dv[0] / dn, dv[1] / dn, dv[2] / dn};
+                if (dn > radius(m1, G1.g_half, a) + radius(m2, G2.g_half, a) + mg) cand = false;
+              }
+#pragma unroll
+              for (int k = 0; k < 3; k++) {
+                const float a1[3] = {m1[k], m1[3 + k], m1[6 + k]}, a2[3] = {m2[k], m2[3 + k], m2[6 + k]};
+                if (fabsf(dot3(dv, a1)) > G1.g_half[k] + radius(m2, G2.g_half, a1) + mg) cand = false;
+                if (fabsf(dot3(dv, a2)) > G2.g_half[k] + radius(m1, G1.g_half, a2) + mg) cand = false;
+              }
+            }
             mesh = cand && (G1.g_type == CS_GEOM_MESH || G2.g_type == CS_GEOM_MESH);
           }
           bool hit = false;
