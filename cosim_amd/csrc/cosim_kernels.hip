@@ -331,34 +331,19 @@ struct Terrain {  // heightfield geometry; (ox, oy) = world position of the loca
   float sx, sy, sz, gz;
   double ox, oy, dx, dy;   // ox, oy already relative to the hfield centre: local x -> field x = x + ox
 };
-// collision triangle t of cell (r, c): {(r,c),(r+1,c),(r,c+1)} / {(r+1,c),(r,c+1),(r+1,c+1)} (prism strip order of
-// mjc_ConvexHField); P0 = first vertex, n = upward unit normal
-__device__ __forceinline__ void terrain_triangle(const Terrain& T, int r, int c, int t, float* P0, float* n) {
-  const int r0 = t ? r + 1 : r, c0 = c, r1 = t ? r : r + 1, c1 = t ? c + 1 : c, r2 = t ? r + 1 : r, c2 = c + 1;
-  const float z0 = T.sz * T.data[r0 * T.ncol + c0], z1 = T.sz * T.data[r1 * T.ncol + c1], z2 = T.sz * T.data[r2 * T.ncol + c2];
-  P0[0] = (float)(c0 * T.dx - (double)T.sx - T.ox); P0[1] = (float)(r0 * T.dy - (double)T.sy - T.oy); P0[2] = z0 + T.gz;
-  const float e1[3] = {(float)((c1 - c0) * T.dx), (float)((r1 - r0) * T.dy), z1 - z0}, e2[3] = {(float)((c2 - c0) * T.dx), (float)((r2 - r0) * T.dy), z2 - z0};
-  cross(n, e1, e2);
-  float s = rsqrtf(dot3(n, n));
-  if (n[2] < 0.f) s = -s;
-  n[0] *= s; n[1] *= s; n[2] *= s;
-}
-// is the world point over triangle t of cell (r, c)?  half-open footprint test in cell coordinates
-__device__ __forceinline__ bool terrain_footprint(const Terrain& T, int r, int c, int t, const float* p) {
-  const double u = ((double)p[0] + T.ox + (double)T.sx) / T.dx - (double)c, w = ((double)p[1] + T.oy + (double)T.sy) / T.dy - (double)r;
-  return u >= 0.0 && u < 1.0 && w >= 0.0 && w < 1.0 && ((t == 0) == (u + w <= 1.0));
-}
-// candidate cells under a bounding sphere (at most 4 x 4 around the centre); returns false when off the field
-__device__ __forceinline__ bool terrain_cells(const Terrain& T, const float* ctr, float rb, int& rmin, int& rmax, int& cmin, int& cmax) {
+// highest terrain vertex under a bounding sphere's footprint (world z); -inf when the sphere is off the field.  Conservative
+// pre-test ahead of the prism walk: a geom whose lowest point is above it cannot touch any prism below it.
+__device__ __forceinline__ float terrain_max_under(const Terrain& T, const float* ctr, float rb) {
   const double lx = (double)ctr[0] + T.ox, ly = (double)ctr[1] + T.oy;
-  if (fabs(lx) - rb > T.sx || fabs(ly) - rb > T.sy) return false;
-  cmin = (int)floor((lx - rb + T.sx) / T.dx); cmax = (int)floor((lx + rb + T.sx) / T.dx);
-  rmin = (int)floor((ly - rb + T.sy) / T.dy); rmax = (int)floor((ly + rb + T.sy) / T.dy);
-  const int cc = (int)floor((lx + T.sx) / T.dx), rc = (int)floor((ly + T.sy) / T.dy);
-  if (cmax - cmin > 3) { cmin = cc - 1; cmax = cc + 2; }
-  if (rmax - rmin > 3) { rmin = rc - 1; rmax = rc + 2; }
-  cmin = max(cmin, 0); rmin = max(rmin, 0); cmax = min(cmax, T.ncol - 2); rmax = min(rmax, T.nrow - 2);
-  return true;
+  if (fabs(lx) - rb > T.sx || fabs(ly) - rb > T.sy) return -3.0e38f;
+  int cmin = (int)floor((lx - rb + T.sx) / T.dx), cmax = (int)ceil((lx + rb + T.sx) / T.dx);
+  int rmin = (int)floor((ly - rb + T.sy) / T.dy), rmax = (int)ceil((ly + rb + T.sy) / T.dy);
+  cmin = max(cmin, 0); rmin = max(rmin, 0); cmax = min(cmax, T.ncol - 1); rmax = min(rmax, T.nrow - 1);
+  cmax = min(cmax, cmin + 12); rmax = min(rmax, rmin + 12);
+  float hmax = 0.f;
+  for (int r = rmin; r <= rmax; r++)
+    for (int c = cmin; c <= cmax; c++) hmax = fmaxf(hmax, T.data[r * T.ncol + c]);
+  return T.gz + T.sz * hmax;
 }
 // terrain elevation under (x, y) on the ray triangulation (mj_rayHfield: cell split along (r,c)-(r+1,c+1)); inside = on the field
 __device__ __forceinline__ float terrain_height(const Terrain& T, float x, float y, bool& inside) {  // (x, y) local
@@ -830,50 +815,43 @@ __global__ __launch_bounds__(64, RPL == 1 ? 4 : 2) void env_kernel(KArgs A) {
           }
           ncon = total;
         } else {
-          // heightfield: contacts are appended through an LDS counter (order: loop iteration, then lane)
+          // heightfield (mjc_ConvexHField): primitives lane-parallel, contacts appended through an LDS counter
           if (ln == 0) S.ncon_ctr = 0;
           WSYNC();
-          int rmin, rmax, cmin, cmax;
-          if (active && terrain_cells(T, ctr, rb, rmin, rmax, cmin, cmax)) {
-            if (gt == CS_GEOM_MESH) mesh_near = true;   // refined per triangle below
-            else {
-              int gcnt = 0;
-              for (int r = rmin; r <= rmax; r++)
-                for (int c = cmin; c <= cmax; c++)
-                  for (int t = 0; t < 2; t++) {
-                    if (gcnt >= 4) continue;
-                    float P0[3], n[3];
-                    terrain_triangle(T, r, c, t, P0, n);
-                    if (n[0] * (ctr[0] - P0[0]) + n[1] * (ctr[1] - P0[1]) + n[2] * (ctr[2] - P0[2]) - rb > margin) continue;
-                    PrimCtx tri;
-                    prim_plane_mask<GTM>(R, xq, xp, P0, n, margin, tri);
-                    unsigned rest = tri.mask;
-#pragma unroll
-                    for (int j = 0; j < 4; j++) {
-                      if (rest) {
-                        const int bit = __builtin_ctz(rest);
-                        rest &= rest - 1;
-                        float dist, cpj[3];
-                        prim_plane_point(tri, n, bit, dist, cpj);
-                        if (gcnt < 4 && terrain_footprint(T, r, c, t, cpj)) {
-                          const int slot = atomicAdd(&S.ncon_ctr, 1);
-                          gcnt++;
-                          if (slot < MC) {
-                            S.cdist[slot] = dist;
-                            S.cgeom[slot] = ln;
-                            S.cpos[slot][0] = cpj[0]; S.cpos[slot][1] = cpj[1]; S.cpos[slot][2] = cpj[2];
-                            if (NRM) { S.cnrm[NRM ? slot : 0][0] = n[0]; S.cnrm[NRM ? slot : 0][1] = n[1]; S.cnrm[NRM ? slot : 0][2] = n[2]; }
-                          }
-                        }
-                      }
-                    }
-                  }
+          // lowest point of the body-frame box around the geom vs the highest terrain vertex under its bounding sphere
+          bool near = false;
+          if (active) {
+            float m[9];
+            q2m(m, xq);
+            const float low = ctr[2] - (fabsf(m[6]) * R.g_half[0] + fabsf(m[7]) * R.g_half[1] + fabsf(m[8]) * R.g_half[2]);
+            near = low - margin <= terrain_max_under(T, ctr, rb);
+          }
+          if (near) {
+            if (gt == CS_GEOM_MESH) mesh_near = true;
+            else if constexpr ((GTM & ~GT_MESH) != 0) {
+              CObj o;
+              o.kind = gt; o.adr = 0; o.num = 0;
+              for (int k = 0; k < 3; k++) o.size[k] = R.g_size[k];
+              {
+                float v[3];
+                qrot(v, xq, R.g_pos);
+                for (int k = 0; k < 3; k++) { o.pos[k] = xp[k] + v[k]; o.center[k] = o.pos[k]; }
+                qmul(o.q, xq, R.g_quat);
+              }
+              hfield_geom<GTM, false>(T, o, ctr, rb, margin, dm.hfield_size[3], A.hull_vert, ln, [&](float dist, const float* pos, const float* n) {
+                const int slot = atomicAdd(&S.ncon_ctr, 1);
+                if (slot < MC) {
+                  S.cdist[slot] = dist;
+                  S.cgeom[slot] = ln;
+                  for (int k = 0; k < 3; k++) { S.cpos[slot][k] = pos[k]; S.cnrm[NRM ? slot : 0][k] = n[k]; }
+                }
+              });
             }
           }
           WSYNC();
           ncon = S.ncon_ctr;
         }
-        // convex meshes near the ground: all lanes scan the hull (mjc_PlaneConvex against the plane / each candidate triangle)
+        // convex meshes near the ground, one at a time, all lanes sharing the scans over the hull's vertices
         unsigned long long mm = __ballot(mesh_near);
         while (mm) {
           const int g = __builtin_ctzll(mm);
@@ -890,55 +868,63 @@ __global__ __launch_bounds__(64, RPL == 1 ? 4 : 2) void env_kernel(KArgs A) {
             qrot(v, gq, G.g_rcenter);
             for (int k = 0; k < 3; k++) gctr[k] = gxp[k] + v[k];
           }
-          int rmin = 0, rmax = 0, cmin = 0, cmax = 0;
-          if (!is_plane && !terrain_cells(T, gctr, grb, rmin, rmax, cmin, cmax)) continue;
-          int gadded = 0;
-          for (int r = rmin; r <= rmax; r++)
-            for (int c = cmin; c <= cmax; c++)
-              for (int t = 0; t < (is_plane ? 1 : 2); t++) {
-                if (gadded >= 4) continue;
-                float P0[3] = {0.f, 0.f, T.gz}, n[3] = {0.f, 0.f, 1.f};
-                if (!is_plane) {
-                  terrain_triangle(T, r, c, t, P0, n);
-                  if (n[0] * (gctr[0] - P0[0]) + n[1] * (gctr[1] - P0[1]) + n[2] * (gctr[2] - P0[2]) - grb > gmargin) continue;
-                }
-                const float lnv[3] = {m[0] * n[0] + m[3] * n[1] + m[6] * n[2], m[1] * n[0] + m[4] * n[1] + m[7] * n[2], m[2] * n[0] + m[5] * n[1] + m[8] * n[2]};  // R^T n
-                const float offn = n[0] * (gxp[0] - P0[0]) + n[1] * (gxp[1] - P0[1]) + n[2] * (gxp[2] - P0[2]);
-                float best = 3.0e38f;
-                int besti = 0x7fffffff;
-                for (int i = ln; i < num; i += 64) {
-                  const float* v = A.hull_vert + 3 * (adr + i);
-                  const float dist = offn + lnv[0] * v[0] + lnv[1] * v[1] + lnv[2] * v[2];
-                  if (dist < best) { best = dist; besti = i; }
-                }
-                const float bmin = wave_min(best);
-                if (!(bmin <= gmargin)) continue;
-                int bi = (best == bmin) ? besti : 0x7fffffff;  // lowest vertex index among ties, like a sequential scan
-#pragma unroll
-                for (int o = 32; o > 0; o >>= 1) bi = min(bi, __shfl_xor(bi, o, 64));
-                int added = 0;
-                for (int pass = 0; pass < 2; pass++) {
-                  const int lo = pass ? A.hull_adr[adr + bi] : 0, hi = pass ? A.hull_adr[adr + bi + 1] : 1;
-                  for (int e = lo; e < hi && added < 4; e++) {
-                    const int i = pass ? A.hull_nbr[e] : bi;
-                    const float* v = A.hull_vert + 3 * (adr + i);
-                    const float dist = offn + lnv[0] * v[0] + lnv[1] * v[1] + lnv[2] * v[2];
-                    if (dist > gmargin) continue;
-                    const float w[3] = {m[0] * v[0] + m[1] * v[1] + m[2] * v[2], m[3] * v[0] + m[4] * v[1] + m[5] * v[2], m[6] * v[0] + m[7] * v[1] + m[8] * v[2]};
-                    const float cpw[3] = {gxp[0] + w[0] - n[0] * dist * 0.5f, gxp[1] + w[1] - n[1] * dist * 0.5f, gxp[2] + w[2] - n[2] * dist * 0.5f};
-                    added++;   // the plane routine's own 4-contact budget (as in the oracle: filtered afterwards)
-                    if (!is_plane && !terrain_footprint(T, r, c, t, cpw)) continue;
-                    if (gadded >= 4) continue;
-                    if (ncon < MC && ln == 0) {
-                      S.cdist[ncon] = dist;
-                      S.cgeom[ncon] = g;
-                      for (int k = 0; k < 3; k++) { S.cpos[ncon][k] = cpw[k]; if (NRM) S.cnrm[NRM ? ncon : 0][k] = n[k]; }
-                    }
-                    ncon++;
-                    gadded++;
-                  }
-                }
+          if constexpr (!is_plane) {
+            CObj o;
+            o.kind = CS_GEOM_MESH; o.adr = adr; o.num = num;
+            for (int k = 0; k < 3; k++) { o.size[k] = 0.f; o.pos[k] = gxp[k]; }
+            for (int k = 0; k < 4; k++) o.q[k] = gq[k];
+            {
+              const float4 ge = A.gext[g];
+              const float cl[3] = {ge.x, ge.y, ge.z};
+              float v[3];
+              qrot(v, gq, cl);
+              for (int k = 0; k < 3; k++) o.center[k] = gxp[k] + v[k];
+            }
+            hfield_geom<GTM, true>(T, o, gctr, grb, gmargin, dm.hfield_size[3], A.hull_vert, ln, [&](float dist, const float* pos, const float* n) {
+              if (ncon < MC && ln == 0) {
+                S.cdist[ncon] = dist;
+                S.cgeom[ncon] = g;
+                for (int k = 0; k < 3; k++) { S.cpos[ncon][k] = pos[k]; S.cnrm[NRM ? ncon : 0][k] = n[k]; }
               }
+              ncon++;
+            });
+            continue;
+          }
+          // plane: mjc_PlaneConvex -- the support vertex, then its hull neighbours within the margin (at most 4 contacts)
+          const float P0[3] = {0.f, 0.f, T.gz}, n[3] = {0.f, 0.f, 1.f};
+          const float lnv[3] = {m[0] * n[0] + m[3] * n[1] + m[6] * n[2], m[1] * n[0] + m[4] * n[1] + m[7] * n[2], m[2] * n[0] + m[5] * n[1] + m[8] * n[2]};  // R^T n
+          const float offn = n[0] * (gxp[0] - P0[0]) + n[1] * (gxp[1] - P0[1]) + n[2] * (gxp[2] - P0[2]);
+          float best = 3.0e38f;
+          int besti = 0x7fffffff;
+          for (int i = ln; i < num; i += 64) {
+            const float* v = A.hull_vert + 3 * (adr + i);
+            const float dist = offn + lnv[0] * v[0] + lnv[1] * v[1] + lnv[2] * v[2];
+            if (dist < best) { best = dist; besti = i; }
+          }
+          const float bmin = wave_min(best);
+          if (!(bmin <= gmargin)) continue;
+          int bi = (best == bmin) ? besti : 0x7fffffff;  // lowest vertex index among ties, like a sequential scan
+#pragma unroll
+          for (int o = 32; o > 0; o >>= 1) bi = min(bi, __shfl_xor(bi, o, 64));
+          int added = 0;
+          for (int pass = 0; pass < 2; pass++) {
+            const int lo = pass ? A.hull_adr[adr + bi] : 0, hi = pass ? A.hull_adr[adr + bi + 1] : 1;
+            for (int e = lo; e < hi && added < 4; e++) {
+              const int i = pass ? A.hull_nbr[e] : bi;
+              const float* v = A.hull_vert + 3 * (adr + i);
+              const float dist = offn + lnv[0] * v[0] + lnv[1] * v[1] + lnv[2] * v[2];
+              if (dist > gmargin) continue;
+              const float w[3] = {m[0] * v[0] + m[1] * v[1] + m[2] * v[2], m[3] * v[0] + m[4] * v[1] + m[5] * v[2], m[6] * v[0] + m[7] * v[1] + m[8] * v[2]};
+              const float cpw[3] = {gxp[0] + w[0] - n[0] * dist * 0.5f, gxp[1] + w[1] - n[1] * dist * 0.5f, gxp[2] + w[2] - n[2] * dist * 0.5f};
+              added++;
+              if (ncon < MC && ln == 0) {
+                S.cdist[ncon] = dist;
+                S.cgeom[ncon] = g;
+                for (int k = 0; k < 3; k++) { S.cpos[ncon][k] = cpw[k]; if (NRM) S.cnrm[NRM ? ncon : 0][k] = n[k]; }
+              }
+              ncon++;
+            }
+          }
         }
       }
 

@@ -19,6 +19,7 @@ namespace cosim {
 constexpr double MPR_EPS = 2.220446049250313e-16;
 constexpr double MPR_TOL = 1e-6;
 constexpr int MPR_MAXIT = 50;
+constexpr int HF_MAXCELLS = 10;   // sub-grid extent walked under one geom (rows, columns)
 
 struct CObj {            // one convex geom, world pose
   int kind;              // CS_GEOM_*
@@ -262,6 +263,97 @@ __device__ __forceinline__ bool mpr_penetration(const SUP& sup, const float* c1,
   depth_out = (float)depth;
   for (int k = 0; k < 3; k++) { dir_f[k] = (float)dir_out[k]; pos_f[k] = (float)pos[k]; }
   return isfinite(depth) && isfinite(pos[0]) && isfinite(pos[1]) && isfinite(pos[2]);
+}
+
+// ------------------------------------------------------------------------------------------------ heightfield prisms
+// mjc_ConvexHField (engine_collision_convex.c): one prism per terrain triangle (top = triangle, bottom at -size[3]),
+// MPR between the prism (geom1) and the robot geom (geom2), at most one contact per prism.
+struct PrismObj { float x[3], y[3], zt[3], zb; };   // strip window: vertex k at (x[k], y[k]), top zt[k], common bottom zb
+
+__device__ __forceinline__ void prism_support(const PrismObj& P, const float* dir, float* out) {   // bottom triangle for dir z < 0, else top
+  const bool bot = dir[2] < 0.f;
+  const float z0 = bot ? P.zb : P.zt[0], z1 = bot ? P.zb : P.zt[1], z2 = bot ? P.zb : P.zt[2];
+  const float t0 = P.x[0] * dir[0] + P.y[0] * dir[1] + z0 * dir[2], t1 = P.x[1] * dir[0] + P.y[1] * dir[1] + z1 * dir[2],
+              t2 = P.x[2] * dir[0] + P.y[2] * dir[1] + z2 * dir[2];
+  const bool b1 = t1 > t0, b2 = t2 > (b1 ? t1 : t0);
+  out[0] = b2 ? P.x[2] : (b1 ? P.x[1] : P.x[0]);
+  out[1] = b2 ? P.y[2] : (b1 ? P.y[1] : P.y[0]);
+  out[2] = b2 ? z2 : (b1 ? z1 : z0);
+}
+
+template <int GTM, bool COOP>
+struct MprPrismGeom {
+  const PrismObj& P;
+  const CObj& g;
+  const float* hull;
+  int ln;
+  __device__ __forceinline__ void operator()(const real* dir, MprSup& s) const {
+    const float fd[3] = {(float)dir[0], (float)dir[1], (float)dir[2]}, nd[3] = {-fd[0], -fd[1], -fd[2]};
+    float v1[3], v2[3];
+    prism_support(P, fd, v1);
+    cobj_support<GTM, COOP>(g, hull, nd, v2, ln);
+    for (int k = 0; k < 3; k++) { s.v1[k] = (real)v1[k]; s.v[k] = (real)v1[k] - (real)v2[k]; }
+  }
+};
+
+// All prisms under one geom.  Coordinates are base-relative (the frame the kernel keeps poses in); T.ox / T.oy carry the
+// base's offset on the field in fp64.  emit(dist, pos, normal) is called once per penetrated prism, in strip order.
+template <int GTM, bool COOP, class EMIT>
+__device__ __forceinline__ void hfield_geom(const Terrain& T, const CObj& o, const float* ctr, float rb, float margin, float base,
+                                            const float* hull, int ln, const EMIT& emit) {
+  // box-sphere early outs
+  const double lx = (double)ctr[0] + T.ox, ly = (double)ctr[1] + T.oy;
+  if ((double)T.sx < lx - rb - margin || -(double)T.sx > lx + rb + margin || (double)T.sy < ly - rb - margin || -(double)T.sy > ly + rb + margin) return;
+  if (T.sz < ctr[2] - T.gz - rb - margin || -base > ctr[2] - T.gz + rb + margin) return;
+  // axis-aligned box of the geom through its support function
+  float lo[3], hi[3];
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    float d[3] = {0.f, 0.f, 0.f}, p[3];
+    d[k] = 1.f;
+    cobj_support<GTM, COOP>(o, hull, d, p, ln);
+    hi[k] = p[k];
+    d[k] = -1.f;
+    cobj_support<GTM, COOP>(o, hull, d, p, ln);
+    lo[k] = p[k];
+  }
+  const double x0 = (double)lo[0] + T.ox, x1 = (double)hi[0] + T.ox, y0 = (double)lo[1] + T.oy, y1 = (double)hi[1] + T.oy;
+  if (x0 - margin > T.sx || x1 + margin < -T.sx || y0 - margin > T.sy || y1 + margin < -T.sy || lo[2] - T.gz - margin > T.sz ||
+      hi[2] - T.gz + margin < -base) return;
+  int cmin = (int)floor((x0 + T.sx) / T.dx), cmax = (int)ceil((x1 + T.sx) / T.dx);
+  int rmin = (int)floor((y0 + T.sy) / T.dy), rmax = (int)ceil((y1 + T.sy) / T.dy);
+  cmin = max(cmin, 0); rmin = max(rmin, 0); cmax = min(cmax, T.ncol - 1); rmax = min(rmax, T.nrow - 1);
+  // cosim_create refuses fields whose cells are small against the geoms; the clamp only bounds the loop for the hardware's sake
+  cmax = min(cmax, cmin + HF_MAXCELLS); rmax = min(rmax, rmin + HF_MAXCELLS);
+  PrismObj P;
+  P.zb = T.gz - base;
+  for (int k = 0; k < 3; k++) { P.x[k] = 0.f; P.y[k] = 0.f; P.zt[k] = 0.f; }
+  int cnt = 0;
+  for (int r = rmin; r < rmax; r++) {
+    int nvert = 0;
+    for (int c = cmin; c <= cmax; c++) {
+      const float xc = (float)(c * T.dx - (double)T.sx - T.ox);
+#pragma unroll
+      for (int i = 0; i < 2; i++) {
+        const int rr = r + 1 - i;   // strip order: (r+1, c) then (r, c)
+        P.x[0] = P.x[1]; P.x[1] = P.x[2]; P.y[0] = P.y[1]; P.y[1] = P.y[2]; P.zt[0] = P.zt[1]; P.zt[1] = P.zt[2];
+        P.x[2] = xc;
+        P.y[2] = (float)(rr * T.dy - (double)T.sy - T.oy);
+        P.zt[2] = T.data[rr * T.ncol + c] * T.sz + T.gz + margin;
+        if (++nvert <= 2) continue;
+        if (P.zt[0] < lo[2] && P.zt[1] < lo[2] && P.zt[2] < lo[2]) continue;
+        if (cnt >= 50) continue;   // mjMAXCONPAIR
+        const float c1[3] = {(P.x[0] + P.x[1] + P.x[2]) * (1.f / 3.f), (P.y[0] + P.y[1] + P.y[2]) * (1.f / 3.f),
+                             (P.zt[0] + P.zt[1] + P.zt[2] + 3.f * P.zb) * (1.f / 6.f)};
+        const MprPrismGeom<GTM, COOP> sup{P, o, hull, ln};
+        float depth = 0.f, n[3] = {0.f, 0.f, 1.f}, pos[3] = {0.f, 0.f, 0.f};
+        if (mpr_penetration(sup, c1, o.center, depth, n, pos) && (n[0] != 0.f || n[1] != 0.f || n[2] != 0.f)) {
+          emit(margin - depth, pos, n);
+          cnt++;
+        }
+      }
+    }
+  }
 }
 
 }  // namespace cosim

@@ -806,69 +806,77 @@ static double hfield_height(const oracle_data* d, double x, double y, int* insid
   return m->ground_pos[2] + sz * h;
 }
 
-/* Heightfield narrowphase.  NOT a restatement of mjc_ConvexHField: MuJoCo runs libccd's MPR between the geom and every
- * triangular prism under the geom's bounding box (one contact per penetrated prism); this build uses a cheaper, fully
- * specified rule: for every collision triangle {(r,c),(r+1,c),(r,c+1)} / {(r+1,c),(r,c+1),(r+1,c+1)} (the prism strip
- * order of mjc_ConvexHField) within the geom's bounding-sphere footprint (at most 4 x 4 cells around the centre), run the
- * *plane* routine of the geom type against the triangle's supporting plane and keep the contacts whose position lies over
- * that triangle (half-open footprint test in cell coordinates, so triangles tile without duplicates).  On a locally flat
- * terrain this reproduces the plane contacts exactly.  At most 4 contacts per geom, in (r, c, triangle) order.
- * The HIP engine implements the same rule. */
+/* Heightfield narrowphase: mjc_ConvexHField (engine_collision_convex.c) restated.  The geom's axis-aligned box in the
+ * hfield frame (six support queries) selects a sub-grid of cells; the cells are walked row by row as a triangle strip --
+ * vertices (r+1, c), (r, c), (r+1, c+1), (r, c+1), ... -- and every three consecutive strip vertices span one prism
+ * (top = terrain triangle, bottom at -size[3]).  Prisms whose top lies entirely below the geom's lowest point are
+ * skipped; each remaining prism is tested against the geom with MPR and contributes at most one contact (normal prism ->
+ * geom); at most mjMAXCONPAIR = 50 contacts per geom.  The ground geom has identity orientation in all four models. */
+#define MAXCONPAIR 50
 static void hfield_collide(oracle_data* d, int g) {
   const cosim_model_t* m = &d->m;
-  int b = m->geom_bodyid[g];
   int nr = m->hfield_nrow, nc = m->hfield_ncol;
-  double sx = m->hfield_size[0], sy = m->hfield_size[1], sz = m->hfield_size[2];
+  const double* size = m->hfield_size;
   double margin = fmax(m->ground_margin, m->geom_margin[g]);
-  double ctr[3], v[3];
-  mul_mat_vec3(v, d->xmat[b], m->geom_rcenter[g]);
-  for (int k = 0; k < 3; k++) ctr[k] = d->xpos[b][k] + v[k] - m->ground_pos[k];
-  double rb = m->geom_rbound[g];
-  if (fabs(ctr[0]) - rb > sx || fabs(ctr[1]) - rb > sy) return;
-  double dx = 2 * sx / (nc - 1), dy = 2 * sy / (nr - 1);
-  int cmin = (int)floor((ctr[0] - rb + sx) / dx), cmax = (int)floor((ctr[0] + rb + sx) / dx);
-  int rmin = (int)floor((ctr[1] - rb + sy) / dy), rmax = (int)floor((ctr[1] + rb + sy) / dy);
-  int cc = (int)floor((ctr[0] + sx) / dx), rc = (int)floor((ctr[1] + sy) / dy);
-  if (cmax - cmin > 3) { cmin = cc - 1; cmax = cc + 2; }
-  if (rmax - rmin > 3) { rmin = rc - 1; rmax = rc + 2; }
+  cobj_t o2, pr;
+  make_cobj(d, g, &o2);
+  for (int k = 0; k < 3; k++) { o2.pos[k] -= m->ground_pos[k]; o2.center[k] -= m->ground_pos[k]; } /* hfield frame */
+  /* box-sphere tests (conservative early outs) */
+  {
+    int b = m->geom_bodyid[g];
+    double v[3], ctr[3], rb = m->geom_rbound[g];
+    mul_mat_vec3(v, d->xmat[b], m->geom_rcenter[g]);
+    for (int k = 0; k < 3; k++) ctr[k] = d->xpos[b][k] + v[k] - m->ground_pos[k];
+    for (int k = 0; k < 2; k++)
+      if (size[k] < ctr[k] - rb - margin || -size[k] > ctr[k] + rb + margin) return;
+    if (size[2] < ctr[2] - rb - margin || -size[3] > ctr[2] + rb + margin) return;
+  }
+  /* axis-aligned box of the geom through its support function */
+  double lo[3], hi[3];
+  for (int k = 0; k < 3; k++) {
+    double dir[3] = {0, 0, 0}, p[3];
+    dir[k] = 1; co_support(&o2, dir, p); hi[k] = p[k];
+    dir[k] = -1; co_support(&o2, dir, p); lo[k] = p[k];
+  }
+  if (lo[0] - margin > size[0] || hi[0] + margin < -size[0] || lo[1] - margin > size[1] || hi[1] + margin < -size[1] ||
+      lo[2] - margin > size[2] || hi[2] + margin < -size[3]) return;
+  int cmin = (int)floor((lo[0] + size[0]) / (2 * size[0]) * (nc - 1)), cmax = (int)ceil((hi[0] + size[0]) / (2 * size[0]) * (nc - 1));
+  int rmin = (int)floor((lo[1] + size[1]) / (2 * size[1]) * (nr - 1)), rmax = (int)ceil((hi[1] + size[1]) / (2 * size[1]) * (nr - 1));
   if (cmin < 0) cmin = 0;
   if (rmin < 0) rmin = 0;
-  if (cmax > nc - 2) cmax = nc - 2;
-  if (rmax > nr - 2) rmax = nr - 2;
-  int first = d->ncon;
-  for (int r = rmin; r <= rmax; r++)
+  if (cmax > nc - 1) cmax = nc - 1;
+  if (rmax > nr - 1) rmax = nr - 1;
+  double dx = 2 * size[0] / (nc - 1), dy = 2 * size[1] / (nr - 1);
+  memset(&pr, 0, sizeof pr);
+  pr.kind = CO_PRISM;
+  const int dr[2] = {1, 0};
+  int cnt = 0;
+  for (int r = rmin; r < rmax; r++) {
+    int nvert = 0;
     for (int c = cmin; c <= cmax; c++)
-      for (int t = 0; t < 2; t++) {
-        if (d->ncon - first >= 4) return;
-        int ri[3] = {t ? r + 1 : r, t ? r : r + 1, t ? r + 1 : r}, ci[3] = {c, t ? c + 1 : c, c + 1};
-        double P[3][3];
-        for (int q = 0; q < 3; q++) {
-          P[q][0] = ci[q] * dx - sx + m->ground_pos[0]; P[q][1] = ri[q] * dy - sy + m->ground_pos[1];
-          P[q][2] = sz * d->hfield[ri[q] * nc + ci[q]] + m->ground_pos[2];
+      for (int i = 0; i < 2; i++) {
+        /* addVert: shift the strip window, new vertex into slot 2 (bottom) / 5 (top) */
+        for (int k = 0; k < 3; k++) {
+          pr.prism[0][k] = pr.prism[1][k]; pr.prism[1][k] = pr.prism[2][k];
+          pr.prism[3][k] = pr.prism[4][k]; pr.prism[4][k] = pr.prism[5][k];
         }
-        double e1[3], e2[3], n[3];
-        for (int k = 0; k < 3; k++) { e1[k] = P[1][k] - P[0][k]; e2[k] = P[2][k] - P[0][k]; }
-        cross3(n, e1, e2);
-        normalize3(n);
-        if (n[2] < 0) { n[0] = -n[0]; n[1] = -n[1]; n[2] = -n[2]; }
-        double dc[3] = {ctr[0] + m->ground_pos[0] - P[0][0], ctr[1] + m->ground_pos[1] - P[0][1], ctr[2] + m->ground_pos[2] - P[0][2]};
-        if (dot3(n, dc) - rb > margin) continue;
-        int before = d->ncon;
-        switch (m->geom_type[g]) {
-          case CS_GEOM_SPHERE: plane_sphere(d, g, P[0], n, margin); break;
-          case CS_GEOM_CYLINDER: plane_cylinder(d, g, P[0], n, margin); break;
-          case CS_GEOM_BOX: plane_box(d, g, P[0], n, margin); break;
-          case CS_GEOM_MESH: plane_mesh(d, g, P[0], n, margin); break;
-          default: break;
+        pr.prism[2][0] = pr.prism[5][0] = dx * c - size[0];
+        pr.prism[2][1] = pr.prism[5][1] = dy * (r + dr[i]) - size[1];
+        pr.prism[2][2] = -size[3];
+        pr.prism[5][2] = d->hfield[(r + dr[i]) * nc + c] * size[2] + margin;
+        if (++nvert <= 2) continue;
+        if (pr.prism[3][2] < lo[2] && pr.prism[4][2] < lo[2] && pr.prism[5][2] < lo[2]) continue;
+        for (int k = 0; k < 3; k++) {
+          pr.center[k] = 0;
+          for (int q = 0; q < 6; q++) pr.center[k] += pr.prism[q][k] / 6.0;
         }
-        int keep = before;
-        for (int i = before; i < d->ncon; i++) { /* footprint filter in cell coordinates */
-          double u = (d->con[i].pos[0] - m->ground_pos[0] + sx) / dx - c, w = (d->con[i].pos[1] - m->ground_pos[1] + sy) / dy - r;
-          int in = u >= 0 && u < 1 && w >= 0 && w < 1 && ((t == 0) == (u + w <= 1));
-          if (in && keep - first < 4) d->con[keep++] = d->con[i];
-        }
-        d->ncon = keep;
+        double depth, dir[3], pos[3];
+        if (mpr_penetration(&pr, &o2, &depth, dir, pos) != 0 || vec_eq0(dir)) continue;
+        for (int k = 0; k < 3; k++) pos[k] += m->ground_pos[k];
+        add_contact(d, g, margin - depth, pos, dir);
+        if (++cnt >= MAXCONPAIR) return;
       }
+  }
 }
 
 /* vertical ray from (x, y, z0) along -z; returns distance or -1 (reference utils/mujoco_utils.py:169 mj_rayHfield) */

@@ -338,10 +338,11 @@ def test_other_robots_one_control_step_replay_flat(env_id, steps):
 
 
 @pytest.mark.parametrize("env_id,terrain,hm", [("flamingo_light_v1", "rocky_hard", False), ("w4_p_v2", "rocky_hard", True),
-                                                ("flamingo_light_v1", "slope_hard", False)])
+                                                ("flamingo_light_v1", "slope_hard", False), ("humanoid_p_v0", "rocky_hard", False)])
 def test_heightfield_terrain_replay_and_height_map(env_id, terrain, hm):
-    """Heightfield ground (config 3: w4_p_v2 on rocky_hard): robots dropped at scattered places of the terrain; one-step
-    replay against the oracle, and the height-map observation against the oracle's vertical ray (mj_rayHfield)."""
+    """Heightfield ground (config 3: w4_p_v2 on rocky_hard): robots dropped at scattered places of the terrain; prism-MPR
+    contacts (mjc_ConvexHField) and one-step replay against the oracle, and the height-map observation against the
+    oracle's vertical ray (mj_rayHfield)."""
     import torch
     from cosim_amd.batched_env import BatchedEnv
     from cosim_amd.compile import compile_model
@@ -352,13 +353,14 @@ def test_heightfield_terrain_replay_and_height_map(env_id, terrain, hm):
     cm = compile_model(cfg)
     b = cm.blob
     assert b.ground_type == 1 and cm.hfield.shape == (512, 512)
+    half = 0.7 * b.hfield_size[0]                                      # scatter over most of the field (64 m or 140 m half-extent)
     rng = np.random.default_rng(11)
     o = Oracle(cm)
     q0 = np.array(get_field(b, "init_qpos")[:b.nq])
     R = dict(qpos=[], qvel=[], warm=[], act=[], qpos1=[], qvel1=[], ncon=[], tilt=[])
     for spot in range(12):
         q = q0.copy()
-        q[0:2] = rng.uniform(-100, 100, size=2)
+        q[0:2] = rng.uniform(-half, half, size=2)
         yaw = rng.uniform(-np.pi, np.pi)
         q[3:7] = [np.cos(yaw / 2), 0, 0, np.sin(yaw / 2)]
         q[2] = q0[2] + (10.0 - o.ray_down(q[0], q[1], 10.0)) + 0.02        # spawn height above the local terrain
@@ -381,8 +383,32 @@ def test_heightfield_terrain_replay_and_height_map(env_id, terrain, hm):
     ok = R["ncon"] <= (12 if b.nv == 18 else 16)
     ep = np.abs(qp - R["qpos1"])[ok].max(axis=1)
     ev = np.abs(qv - R["qvel1"])[ok].max(axis=1)
-    # positions of order 100 m in fp32: 1e-5 m resolution; contact onsets at triangle edges can flip for a few samples
-    assert np.quantile(ep, 0.95) < 2e-4 and np.quantile(ev, 0.95) < 2e-2, (np.quantile(ep, 0.95), np.quantile(ev, 0.95), ep.max(), ev.max())
+    # MPR on a prism ridge is ill-conditioned (the portal lands on either neighbouring face): a few percent of the contacts
+    # get the other face's normal under fp32 poses, so the replay is judged on quantiles, the contact sets below exactly
+    assert np.median(ep) < 2e-5 and np.quantile(ep, 0.9) < 2e-4, (np.median(ep), np.quantile(ep, 0.9), ep.max())
+    assert np.median(ev) < 1e-3 and np.quantile(ev, 0.9) < 2e-2, (np.median(ev), np.quantile(ev, 0.9), ev.max())
+    # --- narrowphase parity (mjc_ConvexHField restatement): same prisms hit, same depth / position / normal
+    env.set_state(R["qpos"], R["qvel"], R["warm"])
+    same_set = tight = total = 0
+    sample = range(0, n, 3)
+    for w in sample:
+        o.reset(R["qpos"][w], R["qvel"][w])
+        o.forward()
+        oc = o.contacts()
+        dbg = env.engine.debug_forward(int(w))
+        nc = min(int(dbg[0]), 16)
+        base = R["qpos"][w][:3].copy(); base[2] = 0.0
+        key = lambda c: (c[0], round(float(c[2][0]), 3), round(float(c[2][1]), 3))
+        gl = sorted([(int(dbg[1900 + i]) & 255, float(dbg[1720 + i]), dbg[1740 + 3 * i:1743 + 3 * i] + base, dbg[1920 + 3 * i:1923 + 3 * i].copy())
+                     for i in range(nc)], key=key)
+        ol = sorted([(int(c[7]), c[0], c[1:4], c[4:7]) for c in oc], key=key)
+        if len(gl) != len(ol) or any(a[0] != c[0] for a, c in zip(gl, ol)):
+            continue
+        same_set += 1
+        for a, c in zip(gl, ol):
+            total += 1
+            tight += abs(a[1] - c[1]) < 2e-5 and np.abs(a[3] - c[3]).max() < 2e-3 and np.abs(a[2] - c[2]).max() < 2e-3
+    assert same_set >= 0.97 * len(sample) and total >= 50 and tight >= 0.93 * total, (same_set, len(sample), tight, total)
     if hm:
         ob = cfg["observation"]["height_map"]
         rx, ry = ob["res_x"], ob["res_y"]
@@ -543,3 +569,11 @@ def test_self_collision_mpr_matches_oracle(env_id, steps, amp):
     ok = (R["nefc"] <= 110) & sc
     assert np.median(ev[ok]) < 2e-4 and np.quantile(ev[ok], 0.9) < 5e-3, (np.median(ev[ok]), np.quantile(ev[ok], 0.9))
     env.close()
+
+
+def test_stairs_class_heightfield_is_refused_loudly():
+    """1 cm heightfield cells (stairs_*): mjc_ConvexHField would emit up to 50 contacts per geom, beyond the engine's rows."""
+    from cosim_amd.batched_env import BatchedEnv
+    from cosim_amd.config import PARITY_RANDOM, make_config
+    with pytest.raises((ValueError, RuntimeError), match="stairs"):
+        BatchedEnv(make_config("flamingo_light_v1", terrain="stairs_up_easy", random=PARITY_RANDOM), num_envs=2)
