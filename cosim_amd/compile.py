@@ -405,7 +405,16 @@ def compile_model(config: dict, model_path: Optional[str] = None) -> CompiledMod
             else:
                 raise ValueError(f"collision geom type '{g['type']}' not supported")
             g_aabb[i, :3] = g["pos"]
-            g_aabb[i, 3:] = g_rbound[i]
+            ar = np.abs(rot)                                     # body-frame box around the oriented primitive
+            if g["type"] == "box":
+                g_aabb[i, 3:] = ar @ np.asarray(s[:3], dtype=np.float64)
+            elif g["type"] == "cylinder":
+                ax = rot[:, 2]
+                g_aabb[i, 3:] = s[1] * np.abs(ax) + s[0] * np.sqrt(np.maximum(0.0, 1.0 - ax * ax))
+            elif g["type"] == "capsule":
+                g_aabb[i, 3:] = s[1] * np.abs(rot[:, 2]) + s[0]
+            else:
+                g_aabb[i, 3:] = g_rbound[i]
             g_center[i] = g["pos"]
 
     def can_collide(a, b):
