@@ -14,8 +14,6 @@
 //   * the nv x nv Newton Hessian is assembled entry-parallel, then factorised in registers (row i in lane i) with
 //     v_readlane broadcasts; reductions use DPP row operations;
 //   * per-env state is one contiguous HBM record, read once and written once per control step.
-#include <type_traits>
-
 #include "cosim_dev.h"
 
 namespace cosim {
@@ -162,12 +160,6 @@ __device__ __forceinline__ unsigned philox_first(unsigned k0, unsigned k1, unsig
 __device__ __forceinline__ float u01(unsigned x) { return (float)(x >> 8) * (1.0f / 16777216.0f) + (0.5f / 16777216.0f); }  // (0,1)
 
 // ------------------------------------------------------------------------------------------------ LDS per env
-struct NarrowWork {   // narrowphase work lists (heightfield prisms per geom, robot-robot mesh pairs)
-  int cnt[32], r0[32], c0[32], nc[32];
-  float lo[32];
-  unsigned pairs[64];
-};
-struct NoWork {};
 template <int NV, int NB, int RPL, bool NRM>   // NRM: contact normals are stored (heightfield ground or robot-robot pairs)
 struct EnvLds {
   static constexpr int LD = NV | 1;   // odd leading dimension: conflict-free column access
@@ -197,7 +189,6 @@ struct EnvLds {
   float sens[10];   // framequat[4], gyro[3], velocimeter[3] of the last substep's forward pass
   float com[3];
   int ncon_ctr;
-  std::conditional_t<NRM, NarrowWork, NoWork> wk;
 };
 
 // ------------------------------------------------------------------------------------------------ Cholesky
@@ -824,110 +815,44 @@ __global__ __launch_bounds__(64, RPL == 1 ? 4 : 2) void env_kernel(KArgs A) {
           }
           ncon = total;
         } else {
-          // heightfield (mjc_ConvexHField).  Phase A, lane = geom: the cells under the geom's oriented box and the number of
-          // prisms of the strip walk over them.  (MuJoCo sizes the sub-grid with the geom's exact support box; a looser box
-          // only adds prisms that MPR then finds separated, so the contacts are the same.)
-          if constexpr (HF) {
-            int np = 0, r0 = 0, c0 = 0, ncell = 0;
-            float lowz = 0.f;
-            if (active) {
-              float m[9], lo[3], hi[3];
-              q2m(m, xq);
-#pragma unroll
-              for (int k = 0; k < 3; k++) {
-                const float ext = fabsf(m[3 * k]) * R.g_half[0] + fabsf(m[3 * k + 1]) * R.g_half[1] + fabsf(m[3 * k + 2]) * R.g_half[2];
-                lo[k] = ctr[k] - ext; hi[k] = ctr[k] + ext;
+          // heightfield (mjc_ConvexHField): primitives lane-parallel, contacts appended through an LDS counter
+          if (ln == 0) S.ncon_ctr = 0;
+          WSYNC();
+          // lowest point of the body-frame box around the geom vs the highest terrain vertex under its bounding sphere
+          bool near = false;
+          if (active) {
+            float m[9];
+            q2m(m, xq);
+            const float low = ctr[2] - (fabsf(m[6]) * R.g_half[0] + fabsf(m[7]) * R.g_half[1] + fabsf(m[8]) * R.g_half[2]);
+            near = low - margin <= terrain_max_under(T, ctr, rb);
+          }
+          if (near) {
+            if (gt == CS_GEOM_MESH) mesh_near = true;
+            else if constexpr ((GTM & ~GT_MESH) != 0) {
+              CObj o;
+              o.kind = gt; o.adr = 0; o.num = 0;
+              for (int k = 0; k < 3; k++) o.size[k] = R.g_size[k];
+              {
+                float v[3];
+                qrot(v, xq, R.g_pos);
+                for (int k = 0; k < 3; k++) { o.pos[k] = xp[k] + v[k]; o.center[k] = o.pos[k]; }
+                qmul(o.q, xq, R.g_quat);
               }
-              lowz = lo[2];
-              const double x0 = (double)lo[0] + T.ox, x1 = (double)hi[0] + T.ox, y0 = (double)lo[1] + T.oy, y1 = (double)hi[1] + T.oy;
-              const float base = dm.hfield_size[3];
-              if (!(x0 - margin > T.sx || x1 + margin < -T.sx || y0 - margin > T.sy || y1 + margin < -T.sy || lo[2] - T.gz - margin > T.sz ||
-                    hi[2] - T.gz + margin < -base)) {
-                int cmin = (int)floor((x0 + T.sx) / T.dx), cmax = (int)ceil((x1 + T.sx) / T.dx);
-                int rmin = (int)floor((y0 + T.sy) / T.dy), rmax = (int)ceil((y1 + T.sy) / T.dy);
-                cmin = max(cmin, 0); rmin = max(rmin, 0); cmax = min(cmax, T.ncol - 1); rmax = min(rmax, T.nrow - 1);
-                // cosim_create refuses fields whose cells are small against the geoms; the clamp only bounds the walk
-                cmax = min(cmax, cmin + HF_MAXCELLS); rmax = min(rmax, rmin + HF_MAXCELLS);
-                if (rmax > rmin && cmax > cmin) {
-                  float hmax = 0.f;
-                  for (int r = rmin; r <= rmax; r++)
-                    for (int c = cmin; c <= cmax; c++) hmax = fmaxf(hmax, T.data[r * T.ncol + c]);
-                  if (lo[2] - margin <= T.gz + T.sz * hmax) { np = (rmax - rmin) * 2 * (cmax - cmin); r0 = rmin; c0 = cmin; ncell = cmax - cmin; }
+              hfield_geom<GTM, false>(T, o, ctr, rb, margin, dm.hfield_size[3], A.hull_vert, ln, [&](float dist, const float* pos, const float* n) {
+                const int slot = atomicAdd(&S.ncon_ctr, 1);
+                if (slot < MC) {
+                  S.cdist[slot] = dist;
+                  S.cgeom[slot] = ln;
+                  for (int k = 0; k < 3; k++) { S.cpos[slot][k] = pos[k]; S.cnrm[NRM ? slot : 0][k] = n[k]; }
                 }
-              }
-            }
-            if (ln < 32) { S.wk.cnt[ln] = np; S.wk.r0[ln] = r0; S.wk.c0[ln] = c0; S.wk.nc[ln] = ncell; S.wk.lo[ln] = lowz; }
-            WSYNC();
-            int total = 0;
-            for (int q = 0; q < ngeom; q++) total += S.wk.cnt[q];
-            // Phase B: one (geom, prism) item per group of GW lanes, in MuJoCo's order (geom, then strip order)
-            constexpr int GW = (GTM & GT_MESH) ? 8 : 1, NG = 64 / GW;
-            const int grp = ln / GW;
-            const bool lead = (ln & (GW - 1)) == 0;
-            for (int ibase = 0; ibase < total; ibase += NG) {
-              const int item = ibase + grp;
-              bool hit = false;
-              int g = 0;
-              float depth = 0.f, cn[3] = {0.f, 0.f, 1.f}, cp[3] = {0.f, 0.f, 0.f};
-              if (item < total) {
-                int acc = 0;
-                for (int q = 0; q < ngeom; q++) {
-                  const int cq = S.wk.cnt[q];
-                  if (item < acc + cq) { g = q; break; }
-                  acc += cq;
-                }
-                const int k = item - acc, nc2 = 2 * S.wk.nc[g];
-                const int r = S.wk.r0[g] + k / nc2, j = k % nc2;
-                PrismObj P;
-                P.zb = T.gz - dm.hfield_size[3];
-                const LaneRec& G = dm.rec[g];
-                const float gmargin = G.g_margin;
-#pragma unroll
-                for (int q = 0; q < 3; q++) {   // strip vertices j, j+1, j+2: (r+1, c), (r, c), (r+1, c+1), (r, c+1), ...
-                  const int jj = j + q, rr = r + 1 - (jj & 1), cc = S.wk.c0[g] + (jj >> 1);
-                  P.x[q] = (float)(cc * T.dx - (double)T.sx - T.ox);
-                  P.y[q] = (float)(rr * T.dy - (double)T.sy - T.oy);
-                  P.zt[q] = T.data[rr * T.ncol + cc] * T.sz + T.gz + gmargin;
-                }
-                const float lowg = S.wk.lo[g];
-                if (!(P.zt[0] < lowg && P.zt[1] < lowg && P.zt[2] < lowg)) {
-                  CObj o;
-                  const int gb = G.g_body;
-                  const float bq[4] = {S.xquat[gb][0], S.xquat[gb][1], S.xquat[gb][2], S.xquat[gb][3]};
-                  o.kind = G.g_type; o.adr = G.g_hulladr; o.num = G.g_hullnum;
-                  for (int q = 0; q < 3; q++) o.size[q] = G.g_size[q];
-                  float v[3];
-                  if (G.g_type == CS_GEOM_MESH) {
-                    const float4 ge = A.gext[g];
-                    const float cl[3] = {ge.x, ge.y, ge.z};
-                    qrot(v, bq, cl);
-                    for (int q = 0; q < 3; q++) { o.pos[q] = S.xpos[gb][q]; o.center[q] = S.xpos[gb][q] + v[q]; }
-                    for (int q = 0; q < 4; q++) o.q[q] = bq[q];
-                  } else {
-                    qrot(v, bq, G.g_pos);
-                    for (int q = 0; q < 3; q++) { o.pos[q] = S.xpos[gb][q] + v[q]; o.center[q] = o.pos[q]; }
-                    qmul(o.q, bq, G.g_quat);
-                  }
-                  const float c1[3] = {(P.x[0] + P.x[1] + P.x[2]) * (1.f / 3.f), (P.y[0] + P.y[1] + P.y[2]) * (1.f / 3.f),
-                                       (P.zt[0] + P.zt[1] + P.zt[2] + 3.f * P.zb) * (1.f / 6.f)};
-                  const MprPrismGeom<GTM, GW> sup{P, o, A.hull_vert, ln};
-                  hit = mpr_penetration(sup, c1, o.center, depth, cn, cp) && (cn[0] != 0.f || cn[1] != 0.f || cn[2] != 0.f);
-                  depth -= gmargin;
-                }
-              }
-              const unsigned long long hm = __ballot(hit && lead);
-              const int slot = ncon + __popcll(hm & lanemask_lt(ln));
-              if (hit && lead && slot < MC) {
-                S.cdist[slot] = -depth;
-                S.cgeom[slot] = g;
-                for (int k = 0; k < 3; k++) { S.cpos[slot][k] = cp[k]; S.cnrm[NRM ? slot : 0][k] = cn[k]; }
-              }
-              ncon += __popcll(hm);
+              });
             }
           }
+          WSYNC();
+          ncon = S.ncon_ctr;
         }
         // convex meshes near the ground, one at a time, all lanes sharing the scans over the hull's vertices
-        unsigned long long mm = is_plane ? __ballot(mesh_near) : 0ull;
+        unsigned long long mm = __ballot(mesh_near);
         while (mm) {
           const int g = __builtin_ctzll(mm);
           mm &= mm - 1;
@@ -942,6 +867,28 @@ __global__ __launch_bounds__(64, RPL == 1 ? 4 : 2) void env_kernel(KArgs A) {
             float v[3];
             qrot(v, gq, G.g_rcenter);
             for (int k = 0; k < 3; k++) gctr[k] = gxp[k] + v[k];
+          }
+          if constexpr (!is_plane) {
+            CObj o;
+            o.kind = CS_GEOM_MESH; o.adr = adr; o.num = num;
+            for (int k = 0; k < 3; k++) { o.size[k] = 0.f; o.pos[k] = gxp[k]; }
+            for (int k = 0; k < 4; k++) o.q[k] = gq[k];
+            {
+              const float4 ge = A.gext[g];
+              const float cl[3] = {ge.x, ge.y, ge.z};
+              float v[3];
+              qrot(v, gq, cl);
+              for (int k = 0; k < 3; k++) o.center[k] = gxp[k] + v[k];
+            }
+            hfield_geom<GTM, true>(T, o, gctr, grb, gmargin, dm.hfield_size[3], A.hull_vert, ln, [&](float dist, const float* pos, const float* n) {
+              if (ncon < MC && ln == 0) {
+                S.cdist[ncon] = dist;
+                S.cgeom[ncon] = g;
+                for (int k = 0; k < 3; k++) { S.cpos[ncon][k] = pos[k]; S.cnrm[NRM ? ncon : 0][k] = n[k]; }
+              }
+              ncon++;
+            });
+            continue;
           }
           // plane: mjc_PlaneConvex -- the support vertex, then its hull neighbours within the margin (at most 4 contacts)
           const float P0[3] = {0.f, 0.f, T.gz}, n[3] = {0.f, 0.f, 1.f};
@@ -1054,7 +1001,7 @@ __global__ __launch_bounds__(64, RPL == 1 ? 4 : 2) void env_kernel(KArgs A) {
               CObj o1, o2;
               make_cobj(o1, g1);
               make_cobj(o2, g2);
-              const MprPair<GTM, 1> sup{o1, o2, A.hull_vert, ln};
+              const MprPair<GTM, false> sup{o1, o2, A.hull_vert, ln};
               hit = mpr_penetration(sup, o1.center, o2.center, depth, cn, cp) && (cn[0] != 0.f || cn[1] != 0.f || cn[2] != 0.f);
             }
           }
@@ -1069,36 +1016,26 @@ __global__ __launch_bounds__(64, RPL == 1 ? 4 : 2) void env_kernel(KArgs A) {
             ncon += __popcll(hm);
           }
           if constexpr ((GTM & GT_MESH) != 0) {
-            // pairs with a hull: compacted into a work list, one pair per group of 8 lanes that share the hull scans
-            const unsigned long long mm = __ballot(mesh);
-            if (mesh) S.wk.pairs[__popcll(mm & lanemask_lt(ln))] = (unsigned)g1 | ((unsigned)g2 << 16);
-            WSYNC();
-            const int nwork = __popcll(mm);
-            for (int ibase = 0; ibase < nwork; ibase += 8) {
-              const int item = ibase + (ln >> 3);
-              bool hit2 = false;
-              int h1 = 0, h2 = 0;
+            unsigned long long mm = __ballot(mesh);
+            while (mm) {
+              const int src = __builtin_ctzll(mm);
+              mm &= mm - 1;
+              const int h1 = __shfl(g1, src, 64), h2 = __shfl(g2, src, 64);
+              CObj o1, o2;
+              make_cobj(o1, h1);
+              make_cobj(o2, h2);
+              const MprPair<GTM, true> sup{o1, o2, A.hull_vert, ln};
               float dep2 = 0.f, n2[3] = {0.f, 0.f, 1.f}, c2[3] = {0.f, 0.f, 0.f};
-              if (item < nwork) {
-                const unsigned pk = S.wk.pairs[item];
-                h1 = pk & 0xffffu; h2 = pk >> 16;
-                CObj o1, o2;
-                make_cobj(o1, h1);
-                make_cobj(o2, h2);
-                const MprPair<GTM, 8> sup{o1, o2, A.hull_vert, ln};
-                hit2 = mpr_penetration(sup, o1.center, o2.center, dep2, n2, c2) && (n2[0] != 0.f || n2[1] != 0.f || n2[2] != 0.f);
+              const bool hit2 = mpr_penetration(sup, o1.center, o2.center, dep2, n2, c2) && (n2[0] != 0.f || n2[1] != 0.f || n2[2] != 0.f);
+              if (hit2) {
+                if (ln == 0 && ncon < MC) {
+                  S.cdist[ncon] = -dep2;
+                  S.cgeom[ncon] = h2 | ((h1 + 1) << 8);
+                  for (int k = 0; k < 3; k++) { S.cpos[ncon][k] = c2[k]; S.cnrm[NRM ? ncon : 0][k] = n2[k]; }
+                }
+                ncon++;
               }
-              const bool lead = (ln & 7) == 0;
-              const unsigned long long hm = __ballot(hit2 && lead);
-              const int slot = ncon + __popcll(hm & lanemask_lt(ln));
-              if (hit2 && lead && slot < MC) {
-                S.cdist[slot] = -dep2;
-                S.cgeom[slot] = h2 | ((h1 + 1) << 8);
-                for (int k = 0; k < 3; k++) { S.cpos[slot][k] = c2[k]; S.cnrm[NRM ? slot : 0][k] = n2[k]; }
-              }
-              ncon += __popcll(hm);
             }
-            WSYNC();
           }
         }
       }

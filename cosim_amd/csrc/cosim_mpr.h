@@ -8,10 +8,10 @@
 // 50 iterations per loop (MuJoCo's ccd_tolerance / ccd_iterations; libccd's refinePortal is uncapped, here every loop is
 // bounded so that every wave reaches the end of the kernel).  oracle/cosim_oracle.c holds the fp64 twin.
 //
-// Work is spread over the wave in groups of GW lanes (template parameter):
-//   * GW = 1: every lane owns one pair of primitives (box / cylinder / sphere supports are O(1));
-//   * GW = 8: every 8 lanes own one pair, hold identical values and share the scan over a mesh hull's vertices in the
-//     support function (control flow inside a group is uniform because its data is), 8 pairs in flight per wave.
+// Two ways to run it, same code:
+//   * lane-parallel: every lane owns one pair of primitives (box / cylinder / sphere supports are O(1));
+//   * wave-cooperative (COOP): all 64 lanes run ONE pair with identical values and share the scan over a mesh hull's
+//     vertices in the support function (control flow is uniform because the data is).
 #pragma once
 
 namespace cosim {
@@ -53,28 +53,23 @@ __device__ __forceinline__ real mpr_normalize(real* v) {
 }
 
 // mjccd_support: furthest point of the geom along the unit world direction
-template <int GTM, int GW>
+template <int GTM, bool COOP>
 __device__ __forceinline__ void cobj_support(const CObj& o, const float* hull, const float* dir, float* out, int ln) {
   const float qi[4] = {o.q[0], -o.q[1], -o.q[2], -o.q[3]};
   float l[3], r[3] = {0.f, 0.f, 0.f};
   qrot(l, qi, dir);
-  if (GW > 1 && (GTM & GT_MESH) && o.kind == CS_GEOM_MESH) {
-    static_assert(GW == 1 || GW == 8, "group width");
+  if (COOP && (GTM & GT_MESH) && o.kind == CS_GEOM_MESH) {
     float best = -3.0e38f;
     int besti = 0x7fffffff;
-    for (int i = ln & (GW - 1); i < o.num; i += GW) {
+    for (int i = ln; i < o.num; i += 64) {
       const float* v = hull + 3 * (o.adr + i);
       const float t = l[0] * v[0] + l[1] * v[1] + l[2] * v[2];
       if (t > best) { best = t; besti = i; }
     }
-    // maximum over the group's 8 lanes (half a DPP row): quad xor 1, quad xor 2, half-row mirror
-    float bmax = fmaxf(best, dpp<0xB1>(best));
-    bmax = fmaxf(bmax, dpp<0x4E>(bmax));
-    bmax = fmaxf(bmax, dpp<0x141>(bmax));
+    const float bmax = -wave_min(-best);
     int bi = (best == bmax) ? besti : 0x7fffffff;   // lowest index among ties, like a sequential scan
-    bi = min(bi, __builtin_amdgcn_update_dpp(0x7fffffff, bi, 0xB1, 0xF, 0xF, false));
-    bi = min(bi, __builtin_amdgcn_update_dpp(0x7fffffff, bi, 0x4E, 0xF, 0xF, false));
-    bi = min(bi, __builtin_amdgcn_update_dpp(0x7fffffff, bi, 0x141, 0xF, 0xF, false));
+#pragma unroll
+    for (int s = 32; s > 0; s >>= 1) bi = min(bi, __shfl_xor(bi, s, 64));
     if (bi >= o.num) bi = 0;
     const float* v = hull + 3 * (o.adr + bi);
     r[0] = v[0]; r[1] = v[1]; r[2] = v[2];
@@ -92,7 +87,7 @@ __device__ __forceinline__ void cobj_support(const CObj& o, const float* hull, c
   out[0] = o.pos[0] + w[0]; out[1] = o.pos[1] + w[1]; out[2] = o.pos[2] + w[2];
 }
 
-template <int GTM, int GW>
+template <int GTM, bool COOP>
 struct MprPair {
   const CObj &a, &b;
   const float* hull;
@@ -100,8 +95,8 @@ struct MprPair {
   __device__ __forceinline__ void operator()(const real* dir, MprSup& s) const {   // __ccdSupport
     const float fd[3] = {(float)dir[0], (float)dir[1], (float)dir[2]}, nd[3] = {-fd[0], -fd[1], -fd[2]};
     float v1[3], v2[3];
-    cobj_support<GTM, GW>(a, hull, fd, v1, ln);
-    cobj_support<GTM, GW>(b, hull, nd, v2, ln);
+    cobj_support<GTM, COOP>(a, hull, fd, v1, ln);
+    cobj_support<GTM, COOP>(b, hull, nd, v2, ln);
     for (int k = 0; k < 3; k++) { s.v1[k] = (real)v1[k]; s.v[k] = (real)v1[k] - (real)v2[k]; }
   }
 };
@@ -286,7 +281,7 @@ __device__ __forceinline__ void prism_support(const PrismObj& P, const float* di
   out[2] = b2 ? z2 : (b1 ? z1 : z0);
 }
 
-template <int GTM, int GW>
+template <int GTM, bool COOP>
 struct MprPrismGeom {
   const PrismObj& P;
   const CObj& g;
@@ -296,9 +291,69 @@ struct MprPrismGeom {
     const float fd[3] = {(float)dir[0], (float)dir[1], (float)dir[2]}, nd[3] = {-fd[0], -fd[1], -fd[2]};
     float v1[3], v2[3];
     prism_support(P, fd, v1);
-    cobj_support<GTM, GW>(g, hull, nd, v2, ln);
+    cobj_support<GTM, COOP>(g, hull, nd, v2, ln);
     for (int k = 0; k < 3; k++) { s.v1[k] = (real)v1[k]; s.v[k] = (real)v1[k] - (real)v2[k]; }
   }
 };
+
+// All prisms under one geom.  Coordinates are base-relative (the frame the kernel keeps poses in); T.ox / T.oy carry the
+// base's offset on the field in fp64.  emit(dist, pos, normal) is called once per penetrated prism, in strip order.
+template <int GTM, bool COOP, class EMIT>
+__device__ __forceinline__ void hfield_geom(const Terrain& T, const CObj& o, const float* ctr, float rb, float margin, float base,
+                                            const float* hull, int ln, const EMIT& emit) {
+  // box-sphere early outs
+  const double lx = (double)ctr[0] + T.ox, ly = (double)ctr[1] + T.oy;
+  if ((double)T.sx < lx - rb - margin || -(double)T.sx > lx + rb + margin || (double)T.sy < ly - rb - margin || -(double)T.sy > ly + rb + margin) return;
+  if (T.sz < ctr[2] - T.gz - rb - margin || -base > ctr[2] - T.gz + rb + margin) return;
+  // axis-aligned box of the geom through its support function
+  float lo[3], hi[3];
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    float d[3] = {0.f, 0.f, 0.f}, p[3];
+    d[k] = 1.f;
+    cobj_support<GTM, COOP>(o, hull, d, p, ln);
+    hi[k] = p[k];
+    d[k] = -1.f;
+    cobj_support<GTM, COOP>(o, hull, d, p, ln);
+    lo[k] = p[k];
+  }
+  const double x0 = (double)lo[0] + T.ox, x1 = (double)hi[0] + T.ox, y0 = (double)lo[1] + T.oy, y1 = (double)hi[1] + T.oy;
+  if (x0 - margin > T.sx || x1 + margin < -T.sx || y0 - margin > T.sy || y1 + margin < -T.sy || lo[2] - T.gz - margin > T.sz ||
+      hi[2] - T.gz + margin < -base) return;
+  int cmin = (int)floor((x0 + T.sx) / T.dx), cmax = (int)ceil((x1 + T.sx) / T.dx);
+  int rmin = (int)floor((y0 + T.sy) / T.dy), rmax = (int)ceil((y1 + T.sy) / T.dy);
+  cmin = max(cmin, 0); rmin = max(rmin, 0); cmax = min(cmax, T.ncol - 1); rmax = min(rmax, T.nrow - 1);
+  // cosim_create refuses fields whose cells are small against the geoms; the clamp only bounds the loop for the hardware's sake
+  cmax = min(cmax, cmin + HF_MAXCELLS); rmax = min(rmax, rmin + HF_MAXCELLS);
+  PrismObj P;
+  P.zb = T.gz - base;
+  for (int k = 0; k < 3; k++) { P.x[k] = 0.f; P.y[k] = 0.f; P.zt[k] = 0.f; }
+  int cnt = 0;
+  for (int r = rmin; r < rmax; r++) {
+    int nvert = 0;
+    for (int c = cmin; c <= cmax; c++) {
+      const float xc = (float)(c * T.dx - (double)T.sx - T.ox);
+#pragma unroll
+      for (int i = 0; i < 2; i++) {
+        const int rr = r + 1 - i;   // strip order: (r+1, c) then (r, c)
+        P.x[0] = P.x[1]; P.x[1] = P.x[2]; P.y[0] = P.y[1]; P.y[1] = P.y[2]; P.zt[0] = P.zt[1]; P.zt[1] = P.zt[2];
+        P.x[2] = xc;
+        P.y[2] = (float)(rr * T.dy - (double)T.sy - T.oy);
+        P.zt[2] = T.data[rr * T.ncol + c] * T.sz + T.gz + margin;
+        if (++nvert <= 2) continue;
+        if (P.zt[0] < lo[2] && P.zt[1] < lo[2] && P.zt[2] < lo[2]) continue;
+        if (cnt >= 50) continue;   // mjMAXCONPAIR
+        const float c1[3] = {(P.x[0] + P.x[1] + P.x[2]) * (1.f / 3.f), (P.y[0] + P.y[1] + P.y[2]) * (1.f / 3.f),
+                             (P.zt[0] + P.zt[1] + P.zt[2] + 3.f * P.zb) * (1.f / 6.f)};
+        const MprPrismGeom<GTM, COOP> sup{P, o, hull, ln};
+        float depth = 0.f, n[3] = {0.f, 0.f, 1.f}, pos[3] = {0.f, 0.f, 0.f};
+        if (mpr_penetration(sup, c1, o.center, depth, n, pos) && (n[0] != 0.f || n[1] != 0.f || n[2] != 0.f)) {
+          emit(margin - depth, pos, n);
+          cnt++;
+        }
+      }
+    }
+  }
+}
 
 }  // namespace cosim
