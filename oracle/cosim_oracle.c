@@ -529,7 +529,9 @@ static void co_support(const cobj_t* o, const double* dir, double* out) {
   for (int k = 0; k < 3; k++) out[k] += o->pos[k];
 }
 
+long g_mpr_calls = 0, g_mpr_supports = 0, g_mpr_hits = 0; /* diagnostics */
 static void mpr_support(const cobj_t* a, const cobj_t* b, const double* dir, csup_t* s) { /* __ccdSupport */
+  g_mpr_supports++;
   double nd[3] = {-dir[0], -dir[1], -dir[2]};
   co_support(a, dir, s->v1);
   co_support(b, nd, s->v2);
@@ -607,6 +609,7 @@ static void mpr_find_pos(const csup_t* P, double* pos) {
 /* ccdMPRPenetration: 0 = penetrating (depth, dir obj1 -> obj2, pos filled), -1 = separated */
 static int mpr_penetration(const cobj_t* o1, const cobj_t* o2, double* depth, double* dir_out, double* pos) {
   csup_t P[4], v4;
+  g_mpr_calls++;
   double dir[3], va[3], vb[3], dot;
   /* --- discoverPortal */
   for (int k = 0; k < 3; k++) { P[0].v1[k] = o1->center[k]; P[0].v2[k] = o2->center[k]; P[0].v[k] = P[0].v1[k] - P[0].v2[k]; }
@@ -1549,6 +1552,7 @@ int oracle_mpr_pair(oracle_data* d, int g1, int g2, double* out7) {
   return mpr_penetration(&o1, &o2, out7, out7 + 1, out7 + 4);
 }
 void oracle_set_self_collision(oracle_data* d, int on) { d->no_self_collision = !on; }
+void oracle_mpr_stats(long* out3) { out3[0] = g_mpr_calls; out3[1] = g_mpr_supports; out3[2] = g_mpr_hits; }
 /* MPR between two primitives given directly (kind: CO_SPHERE/CO_CYLINDER/CO_BOX; pose = pos3 + row-major mat9; size3) */
 int oracle_mpr_prims(int k1, const double* pose1, const double* size1, int k2, const double* pose2, const double* size2, double* out7) {
   cobj_t o1, o2;
