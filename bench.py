@@ -76,18 +76,35 @@ def cpu_baseline(sample_envs=16, sample_steps=12000):
         phi = rng.uniform(0, 2 * np.pi, size=4)
         acts = np.clip(0.25 * np.sin(2 * np.pi * 0.5 * 0.02 * np.arange(sample_steps)[:, None] + phi[None]), -1, 1)
         t0 = time.perf_counter()
-        for t in range(sample_steps):
-            o.control_step(acts[t])
+        n_steps += o.rollout(acts)            # the whole rollout inside one C call
         t_total += time.perf_counter() - t0
-        n_steps += sample_steps
+    # the same port on several host threads (one env per thread; ctypes releases the GIL inside the C step)
+    from concurrent.futures import ThreadPoolExecutor
+    nthr = max(1, min(16, os.cpu_count() or 1))
+    mt_steps = 12000
+
+    def worker(seed):
+        r = np.random.default_rng(1000 + seed)
+        o = Oracle(cm)
+        q = q0.copy()
+        q[[7, 10, 9, 12]] += r.uniform(-0.05, 0.05, size=4)
+        o.reset(q)
+        phi = r.uniform(0, 2 * np.pi, size=4)
+        acts = np.clip(0.25 * np.sin(2 * np.pi * 0.5 * 0.02 * np.arange(mt_steps)[:, None] + phi[None]), -1, 1)
+        return o.rollout(acts)
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(nthr) as ex:
+        done = sum(ex.map(worker, range(nthr)))
+    t_mt = time.perf_counter() - t0
     try:
         import mujoco  # noqa: F401
-        ref = "mujoco importable on this host (reference path not timed by this build)"
+        ref = "mujoco importable on this host: tools/crosscheck_mujoco.py compares and times it (not run by bench.py)"
     except Exception:
         ref = "reference MuJoCo CPU path unavailable on this host"
     return {"value": n_steps / t_total, "unit": "env-steps/s", "cores": 1, "kind": "port",
             "sample": f"{sample_envs} envs x {sample_steps} control steps of {ROBOT} flat, sinusoid actions, fp64 oracle, "
-                      f"1 thread of {os.cpu_count()} host cores ({t_total:.1f} s); {ref}"}
+                      f"1 thread of {os.cpu_count()} host cores ({t_total:.1f} s); {ref}",
+            "threads": {"value": done / t_mt, "cores": nthr, "sample": f"{nthr} threads x 1 env x {mt_steps} control steps ({t_mt:.1f} s)"}}
 
 
 def pmc_traffic(workload):

@@ -1544,6 +1544,14 @@ void oracle_contact(oracle_data* d, int i, double* out) {
   out[7] = c->geom; out[8] = c->efc_address; out[9] = c->geom1;
 }
 
+/* nsteps control steps in one call (actions[nsteps][nu], already delay-filtered): the timing loop of bench.py's CPU leg */
+int oracle_rollout(oracle_data* d, const double* actions, int nsteps) {
+  double tq[CS_MAXU];
+  int t;
+  for (t = 0; t < nsteps && !d->bad; t++) oracle_control_step(d, actions + (size_t)t * d->m.nu, tq);
+  return t;
+}
+
 /* test hooks: one MPR query between two robot geoms (returns 0 when penetrating); self-collision switch */
 int oracle_mpr_pair(oracle_data* d, int g1, int g2, double* out7) {
   cobj_t o1, o2;

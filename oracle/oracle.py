@@ -48,6 +48,7 @@ def lib():
         L.oracle_reset.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
         L.oracle_contact.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
         L.oracle_control_step.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+        L.oracle_rollout.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
         L.oracle_mpr_pair.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
         L.oracle_mpr_prims.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
                                        ctypes.c_void_p]
@@ -168,6 +169,12 @@ class Oracle:
         tq = np.zeros(self.nu)
         self.L.oracle_control_step(self.h, a.ctypes.data, tq.ctypes.data)
         return tq
+
+    def rollout(self, actions: np.ndarray) -> int:
+        """len(actions) control steps inside one C call; returns the steps done (stops early on a bad state)."""
+        a = np.ascontiguousarray(actions, dtype=np.float64)
+        assert a.ndim == 2 and a.shape[1] == self.cm.blob.nu
+        return int(self.L.oracle_rollout(self.h, a.ctypes.data, a.shape[0]))
 
     def ray_down(self, x: float, y: float, z0: float) -> float:
         return self.L.oracle_ray_down(self.h, x, y, z0)
