@@ -12,6 +12,8 @@ from __future__ import annotations
 
 from typing import Dict, Optional
 
+import os
+
 import numpy as np
 
 from . import rng as crng
@@ -100,6 +102,13 @@ class BatchedEnv:
         self.engine = Engine(self.cm, obs_cfg, self.num_envs, dev, self.seed, self.env_id0)
         assert self.engine.query("state_dim") == self.state_dim
         self.info_dim = self.engine.query("info_dim")
+        # kernel variant: COSIM_ENVS_PER_WAVE=1|2 overrides the engine's choice where the variant exists (A/B runs)
+        epw = os.environ.get("COSIM_ENVS_PER_WAVE")
+        if epw:
+            try:
+                self.engine.set_param("envs_per_wave", np.array([float(epw)]))
+            except (ValueError, RuntimeError):
+                pass
 
         self._randomise(gain_noise)
 

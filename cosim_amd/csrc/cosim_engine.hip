@@ -52,6 +52,8 @@ struct cosim_engine {
   int t_launches = 0;
   void (*launch)(cosim_engine*, const KArgs&, int grid, hipStream_t) = nullptr;
   void (*launch_prof)(cosim_engine*, const KArgs&, int grid, hipStream_t) = nullptr;  // diagnostic build (light_v1 flat only)
+  void (*launch2)(cosim_engine*, const KArgs&, int grid, hipStream_t) = nullptr;      // two environments per wave (reset / step)
+  int epw = 1;   // environments per wave of the reset / step launches
   int lds_bytes = 0;
 };
 
@@ -62,6 +64,10 @@ static void launch_t(cosim_engine* e, const KArgs& a, int grid, hipStream_t s) {
 template <int NV, int NB, int RPL, int GTM>
 static void launch_prof_t(cosim_engine* e, const KArgs& a, int grid, hipStream_t s) {
   hipLaunchKernelGGL((env_kernel<NV, NB, RPL, false, GTM, false, true>), dim3(grid), dim3(64), 0, s, a);
+}
+template <int NV, int NB, int GTM>
+static void launch2_t(cosim_engine* e, const KArgs& a, int grid, hipStream_t s) {   // grid = number of envs
+  hipLaunchKernelGGL((env_kernel<NV, NB, 2, false, GTM, false, false, 2>), dim3((grid + 1) / 2), dim3(64), 0, s, a);
 }
 template <int NV, int NB, int RPL, int GTM, bool SC>
 static void select_t(cosim_engine* e, bool hf) {
@@ -324,7 +330,7 @@ int cosim_create(const cosim_model_t* model, const float* hull_vert, const int* 
     }
   }
   constexpr int G_LIGHT = GT_SPHERE | GT_CYLINDER | GT_MESH, G_MESH = GT_MESH, G_HUM = GT_BOX | GT_CYLINDER | GT_MESH;
-  if (nv == 18 && nb <= 14 && (gtm & ~G_LIGHT) == 0) { select_t<18, 14, 1, G_LIGHT, false>(e, hf); if (!hf) e->launch_prof = launch_prof_t<18, 14, 1, G_LIGHT>; }   // flamingo_light_v1
+  if (nv == 18 && nb <= 14 && (gtm & ~G_LIGHT) == 0) { select_t<18, 14, 1, G_LIGHT, false>(e, hf); if (!hf) { e->launch_prof = launch_prof_t<18, 14, 1, G_LIGHT>; e->launch2 = launch2_t<18, 14, G_LIGHT>; } }   // flamingo_light_v1
   else if (nv == 14 && nb <= 10 && (gtm & ~G_MESH) == 0) select_t<14, 10, 2, G_MESH, true>(e, hf);   // flamingo_p_v3
   else if (nv == 22 && nb <= 18 && (gtm & ~G_MESH) == 0) select_t<22, 18, 2, G_MESH, true>(e, hf);   // w4_p_v2
   else if (nv == 29 && nb <= 26 && (gtm & ~G_HUM) == 0) select_t<29, 26, 2, G_HUM, true>(e, hf);     // humanoid_p_v0
@@ -426,6 +432,12 @@ int cosim_set_param(cosim_engine_t* e, const char* name, const float* host, int 
   else if (n == "solver_tolerance") { e->tol32 = host[0]; return COSIM_OK; }
   else if (n == "max_newton") { e->max_newton = (int)host[0]; return COSIM_OK; }
   else if (n == "max_ls") { e->max_ls = (int)host[0]; return COSIM_OK; }
+  else if (n == "envs_per_wave") {   // 2: the two-environments-per-wave kernel (flat flamingo_light_v1, even env counts); 1: one per wave
+    const int w = (int)host[0];
+    if (w != 1 && !(w == 2 && e->launch2 && e->n_envs % 2 == 0)) return fail(COSIM_EINVAL, "cosim_set_param: envs_per_wave not available for this model / env count");
+    e->epw = w;
+    return COSIM_OK;
+  }
   else return fail(COSIM_EINVAL, "cosim_set_param: unknown parameter " + n);
   if (count != e->n_envs * width) return fail(COSIM_EINVAL, "cosim_set_param: " + n + " expects n_envs*" + std::to_string(width) + " values");
   for (int i = 0; i < e->n_envs; i++)
@@ -464,7 +476,7 @@ int cosim_reset(cosim_engine_t* e, const uint8_t* mask_dev, const float* command
   if (rc) return rc;
   KArgs a = base_args(e);
   a.mode = MODE_RESET; a.mask = mask_dev; a.commands = commands_dev; a.state_out = state_out_dev;
-  e->launch(e, a, e->n_envs, (hipStream_t)stream);
+  (e->epw == 2 ? e->launch2 : e->launch)(e, a, e->n_envs, (hipStream_t)stream);
   HIP_TRY(hipGetLastError());
   return COSIM_OK;
 }
@@ -491,7 +503,7 @@ int cosim_step(cosim_engine_t* e, const float* actions_dev, const float* command
     e->ev_used += 2;
     HIP_TRY(hipEventRecord(e->ev[slot], s));
   }
-  e->launch(e, a, e->n_envs, s);
+  (e->epw == 2 ? e->launch2 : e->launch)(e, a, e->n_envs, s);
   HIP_TRY(hipGetLastError());
   if (slot >= 0) HIP_TRY(hipEventRecord(e->ev[slot + 1], s));
   return COSIM_OK;

@@ -93,6 +93,37 @@ __device__ __forceinline__ float wave_min(float v) {
   return fminf(fminf(rl(v, 0), rl(v, 16)), fminf(rl(v, 32), rl(v, 48)));
 }
 __device__ __forceinline__ unsigned long long lanemask_lt(int lane) { return (1ull << lane) - 1ull; }
+// The same operations over a group of LW lanes = one environment (LW = 64: the whole wave; LW = 32: two environments per
+// wave, lanes 0-31 and 32-63).  hb = first lane of the caller's group.
+template <int LW>
+__device__ __forceinline__ float grp_sum(float v) {
+  if constexpr (LW == 64) return wave_sum(v);
+  else {
+    v = row_sum(v);
+    return v + __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v), 0x401F));   // partner row of the 32-lane group (xor 16)
+  }
+}
+template <int LW>
+__device__ __forceinline__ float grp_min(float v) {
+  if constexpr (LW == 64) return wave_min(v);
+  else {
+    v = fminf(v, dpp<0xB1>(v));
+    v = fminf(v, dpp<0x4E>(v));
+    v = fminf(v, dpp<0x141>(v));
+    v = fminf(v, dpp<0x140>(v));
+    return fminf(v, __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v), 0x401F)));
+  }
+}
+template <int LW>
+__device__ __forceinline__ unsigned long long grp_ballot(bool p, int hb) {
+  if constexpr (LW == 64) return __ballot(p);
+  else return (__ballot(p) >> hb) & 0xffffffffull;
+}
+template <int LW>
+__device__ __forceinline__ float grp_bcast(float v, int j, int hb) {   // value of lane j of the group, j the same in the whole group
+  if constexpr (LW == 64) return rl(v, j);
+  else return __shfl(v, j + hb, 64);
+}
 
 // ------------------------------------------------------------------------------------------------ small math
 __device__ __forceinline__ void qmul(float* r, const float* a, const float* b) {
@@ -160,13 +191,13 @@ __device__ __forceinline__ unsigned philox_first(unsigned k0, unsigned k1, unsig
 __device__ __forceinline__ float u01(unsigned x) { return (float)(x >> 8) * (1.0f / 16777216.0f) + (0.5f / 16777216.0f); }  // (0,1)
 
 // ------------------------------------------------------------------------------------------------ LDS per env
-template <int NV, int NB, int RPL, bool NRM>   // NRM: contact normals are stored (heightfield ground or robot-robot pairs)
+template <int NV, int NB, int RPL, bool NRM, int LW = 64>   // NRM: contact normals are stored (heightfield ground or robot-robot pairs)
 struct EnvLds {
   static constexpr int LD = NV | 1;   // odd leading dimension: conflict-free column access
-  static constexpr int ROWS = 64 * RPL;            // constraint rows per env: RPL rows per lane
-  static constexpr int MC = RPL == 1 ? 12 : 16;    // contact slots (4 pyramid rows each)
+  static constexpr int ROWS = LW * RPL;            // constraint rows per env: RPL rows per lane, LW lanes per env
+  static constexpr int MC = ROWS <= 64 ? 12 : 16;  // contact slots (4 pyramid rows each)
   static constexpr int NGEN = 3 * MAXEQ / 2 + 4 * MC;  // dense rows: 2 connect equalities (6 rows) + contacts
-  static constexpr int NLIM = 8 * RPL;
+  static constexpr int NLIM = ROWS / 8;
   float qpos[CS_MAXQ], qvel[NV], qacc[NV], qact[NV], qsm[NV], qcon[NV], sr[NV], dofD[NV];
   float xpos[NB][3], xquat[NB][4], xanc[NB][3], xax[NB][3];
   float cdof[NV][6];
@@ -195,32 +226,32 @@ struct EnvLds {
 // Lane i < NV holds row i of a symmetric positive definite matrix in a[0..NV).  Right-looking factorisation with the
 // pivot column broadcast by v_readlane; only the lower triangle is meaningful on exit (a[k], k <= i, is L[i][k]; slots
 // k > i hold garbage, which is why no lane masking is needed: 2 VALU per (j,k) pair).  dinv is 1 / L[i][i].
-template <int NV>
-__device__ __forceinline__ void chol_lower(float (&a)[NV], float& dinv, int lane) {
+template <int NV, int LW>
+__device__ __forceinline__ void chol_lower(float (&a)[NV], float& dinv, int lane, int hb) {
 #pragma unroll
   for (int j = 0; j < NV; j++) {
-    const float ajj = rl(a[j], j);
+    const float ajj = grp_bcast<LW>(a[j], j, hb);
     const float inv = rsqrtf(fmaxf(ajj, 1e-30f));
     dinv = (lane == j) ? inv : dinv;
     a[j] *= inv;  // column j of L in lanes >= j
 #pragma unroll
-    for (int k = j + 1; k < NV; k++) a[k] -= a[j] * rl(a[j], k);  // rl(a[j], k) = L[k][j]
+    for (int k = j + 1; k < NV; k++) a[k] -= a[j] * grp_bcast<LW>(a[j], k, hb);  // lane k's a[j] = L[k][j]
   }
 }
 // solve (L L^T) x = b with L stored row-major in LDS (Lm[i][k], k <= i valid); lane i holds b_i and returns x_i.
 // Forward substitution reads row i, backward substitution reads column i (consecutive lanes -> consecutive banks).
-template <int NV, int LD>
-__device__ __forceinline__ float chol_solve_lds(const float (*Lm)[LD], float dinv, float b, int lane) {
+template <int NV, int LD, int LW>
+__device__ __forceinline__ float chol_solve_lds(const float (*Lm)[LD], float dinv, float b, int lane, int hb) {
   const int li = lane < NV ? lane : 0;
 #pragma unroll
   for (int j = 0; j < NV; j++) {
-    const float yj = rl(b, j) * rl(dinv, j);
+    const float yj = grp_bcast<LW>(b, j, hb) * grp_bcast<LW>(dinv, j, hb);
     const float upd = b - Lm[li][j] * yj;
     b = (lane == j) ? yj : ((lane > j) ? upd : b);
   }
 #pragma unroll
   for (int j = NV - 1; j >= 0; j--) {
-    const float xj = rl(b, j) * rl(dinv, j);
+    const float xj = grp_bcast<LW>(b, j, hb) * grp_bcast<LW>(dinv, j, hb);
     const float upd = b - Lm[j][li] * xj;
     b = (lane == j) ? xj : ((lane < j) ? upd : b);
   }
@@ -378,19 +409,25 @@ __device__ __forceinline__ float impedance(const float* solimp, float pos, float
 }
 
 // ------------------------------------------------------------------------------------------------ the kernel
-// HF: heightfield ground; SC: robot-robot (self) collision pairs; PROF: diagnostic build with s_memtime phase stamps
-template <int NV, int NB, int RPL, bool HF, int GTM, bool SC, bool PROF = false>
-__global__ __launch_bounds__(64, RPL == 1 ? 4 : 2) void env_kernel(KArgs A) {
+// HF: heightfield ground; SC: robot-robot (self) collision pairs; PROF: diagnostic build with s_memtime phase stamps;
+// EPW: environments per wave (1: lane l of 64 plays object l; 2: two groups of 32 lanes, RPL rows per lane of the group)
+template <int NV, int NB, int RPL, bool HF, int GTM, bool SC, bool PROF = false, int EPW = 1>
+__global__ __launch_bounds__(64, (RPL == 1 && EPW == 1) ? 4 : 2) void env_kernel(KArgs A) {
+  static_assert(EPW == 1 || (EPW == 2 && !HF && !SC && !PROF && NV <= 32 && NB <= 32), "two environments per wave: flat ground, no pairs");
   constexpr bool NRM = HF || SC;
-  using L = EnvLds<NV, NB, RPL, NRM>;
+  constexpr int LW = 64 / EPW;
+  using L = EnvLds<NV, NB, RPL, NRM, LW>;
   constexpr int MAXROWS = L::ROWS;
   constexpr int TRI = NV * (NV + 1) / 2;
   constexpr int MC = L::MC;
   constexpr int NGENMAX = L::NGEN;
   constexpr int EPL = (TRI + 63) / 64;
-  __shared__ L S;
-  const int lane = threadIdx.x;
-  const int env = A.mode == MODE_DEBUG ? A.dbg_env : blockIdx.x;
+  __shared__ L SS[EPW];
+  const int wlane = threadIdx.x;
+  const int hb = EPW == 1 ? 0 : (wlane & 32);          // first lane of this lane's group
+  const int lane = EPW == 1 ? wlane : (wlane & 31);     // role index inside the group
+  L& S = SS[EPW == 1 ? 0 : (wlane >> 5)];
+  const int env = A.mode == MODE_DEBUG ? A.dbg_env : (int)blockIdx.x * EPW + (EPW == 1 ? 0 : (wlane >> 5));
   if (env >= A.n_envs) return;
   const DevModel& dm = *A.dm;
   const DevObs& ob = *A.ob;
@@ -557,7 +594,7 @@ __global__ __launch_bounds__(64, RPL == 1 ? 4 : 2) void env_kernel(KArgs A) {
           q2m(ximat, qi);
           bmass = S.p_mass[b];
         }
-        const float sx = wave_sum(bmass * xip[0]), sy = wave_sum(bmass * xip[1]), sz = wave_sum(bmass * xip[2]), sm = wave_sum(bmass);
+        const float sx = grp_sum<LW>(bmass * xip[0]), sy = grp_sum<LW>(bmass * xip[1]), sz = grp_sum<LW>(bmass * xip[2]), sm = grp_sum<LW>(bmass);
         const float inv = 1.f / fmaxf(sm, 1e-20f);
         const float c0 = sx * inv, c1 = sy * inv, c2 = sz * inv;
         if (ln == 0) { S.com[0] = c0; S.com[1] = c1; S.com[2] = c2; }
@@ -790,7 +827,7 @@ __global__ __launch_bounds__(64, RPL == 1 ? 4 : 2) void env_kernel(KArgs A) {
           int off = 0, total = 0;
 #pragma unroll
           for (int s2 = 0; s2 < 4; s2++) {
-            unsigned long long mk = __ballot(cnt > s2);
+            unsigned long long mk = grp_ballot<LW>(cnt > s2, hb);
             off += __popcll(mk & lanemask_lt(ln));
             total += __popcll(mk);
           }
@@ -852,7 +889,7 @@ __global__ __launch_bounds__(64, RPL == 1 ? 4 : 2) void env_kernel(KArgs A) {
           ncon = S.ncon_ctr;
         }
         // convex meshes near the ground, one at a time, all lanes sharing the scans over the hull's vertices
-        unsigned long long mm = __ballot(mesh_near);
+        unsigned long long mm = grp_ballot<LW>(mesh_near, hb);
         while (mm) {
           const int g = __builtin_ctzll(mm);
           mm &= mm - 1;
@@ -896,16 +933,16 @@ __global__ __launch_bounds__(64, RPL == 1 ? 4 : 2) void env_kernel(KArgs A) {
           const float offn = n[0] * (gxp[0] - P0[0]) + n[1] * (gxp[1] - P0[1]) + n[2] * (gxp[2] - P0[2]);
           float best = 3.0e38f;
           int besti = 0x7fffffff;
-          for (int i = ln; i < num; i += 64) {
+          for (int i = ln; i < num; i += LW) {
             const float* v = A.hull_vert + 3 * (adr + i);
             const float dist = offn + lnv[0] * v[0] + lnv[1] * v[1] + lnv[2] * v[2];
             if (dist < best) { best = dist; besti = i; }
           }
-          const float bmin = wave_min(best);
+          const float bmin = grp_min<LW>(best);
           if (!(bmin <= gmargin)) continue;
           int bi = (best == bmin) ? besti : 0x7fffffff;  // lowest vertex index among ties, like a sequential scan
 #pragma unroll
-          for (int o = 32; o > 0; o >>= 1) bi = min(bi, __shfl_xor(bi, o, 64));
+          for (int o = LW / 2; o > 0; o >>= 1) bi = min(bi, __shfl_xor(bi, o, 64));
           int added = 0;
           for (int pass = 0; pass < 2; pass++) {
             const int lo = pass ? A.hull_adr[adr + bi] : 0, hi = pass ? A.hull_adr[adr + bi + 1] : 1;
@@ -1055,7 +1092,7 @@ __global__ __launch_bounds__(64, RPL == 1 ? 4 : 2) void env_kernel(KArgs A) {
           lo_v = dlo < R.j_margin;
           hi_v = dhi < R.j_margin;
         }
-        unsigned long long ml = __ballot(lo_v), mh = __ballot(hi_v);
+        unsigned long long ml = grp_ballot<LW>(lo_v, hb), mh = grp_ballot<LW>(hi_v, hb);
         int rlo = __popcll(ml & lanemask_lt(ln)), rhi = __popcll(ml) + __popcll(mh & lanemask_lt(ln));
         nl = __popcll(ml) + __popcll(mh);
         if (nl > L::NLIM) nl = L::NLIM;
@@ -1073,12 +1110,12 @@ __global__ __launch_bounds__(64, RPL == 1 ? 4 : 2) void env_kernel(KArgs A) {
       const int nefc = ngen + nf + nl;      // then unit rows: frictionloss, limits
       WSYNC();
 
-      // per-lane row state: row (ln + 64 rr), rr < RPL
+      // per-lane row state: row (ln + LW rr), rr < RPL
       int rtype[RPL], rdof[RPL];
       float rsign[RPL], rfloss[RPL], rD[RPL], rR[RPL], raref[RPL], rpos_dbg = 0.f;
 #pragma unroll
       for (int rr = 0; rr < RPL; rr++) {
-        const int row = ln + 64 * rr;
+        const int row = ln + LW * rr;
         rtype[rr] = RT_NONE; rdof[rr] = 0; rsign[rr] = 1.f; rfloss[rr] = 0.f; rD[rr] = 0.f; rR[rr] = 1.f; raref[rr] = 0.f;
         float rpos = 0.f, rmargin = 0.f, rdiagA = 0.f, rmu = 0.f;
         float rsolref[2] = {0.02f, 1.f}, rsolimp[5] = {0.9f, 0.95f, 0.001f, 0.5f, 2.f};
@@ -1207,10 +1244,10 @@ __global__ __launch_bounds__(64, RPL == 1 ? 4 : 2) void env_kernel(KArgs A) {
         }
         return s;
       };
-      auto rowdot = [&](const float* v, int rr) -> float {  // J[row] . v for row (ln + 64 rr)
+      auto rowdot = [&](const float* v, int rr) -> float {  // J[row] . v for row (ln + LW rr)
         float s = 0.f;
         if (rtype[rr] == RT_EQ || rtype[rr] == RT_CONTACT) {
-          const float* Jr = S.J[ln + 64 * rr];
+          const float* Jr = S.J[ln + LW * rr];
 #pragma unroll
           for (int d = 0; d < NV; d++) s += Jr[d] * v[d];
         } else if (rtype[rr] == RT_FRIC || rtype[rr] == RT_LIMIT) s = rsign[rr] * v[rdof[rr]];
@@ -1248,15 +1285,15 @@ __global__ __launch_bounds__(64, RPL == 1 ? 4 : 2) void env_kernel(KArgs A) {
           }
           dact_cur[rr] = dact;
           csum += c;
-          S.w.r.rowf[ln + 64 * rr] = f;
-          S.w.r.rowD[ln + 64 * rr] = dact;
+          S.w.r.rowf[ln + LW * rr] = f;
+          S.w.r.rowD[ln + LW * rr] = dact;
         }
         WSYNC();
 #pragma unroll
         for (int rr = 0; rr < RPL; rr++)
           if (rtype[rr] == RT_FRIC || rtype[rr] == RT_LIMIT) {
             atomicAdd(&S.dofD[rdof[rr]], dact_cur[rr]);
-            atomicAdd(&S.qcon[rdof[rr]], rsign[rr] * S.w.r.rowf[ln + 64 * rr]);
+            atomicAdd(&S.qcon[rdof[rr]], rsign[rr] * S.w.r.rowf[ln + LW * rr]);
           }
         WSYNC();
         float qc = 0.f;
@@ -1265,28 +1302,32 @@ __global__ __launch_bounds__(64, RPL == 1 ? 4 : 2) void env_kernel(KArgs A) {
           for (int r = 0; r < ngen; r++) qc += S.J[r][ln] * S.w.r.rowf[r];
           S.qcon[ln] = qc;
         }
-        gauss = wave_sum(ln < NV ? (0.5f * Ma - qsm_l) * qacc_l : 0.f);
-        cost = wave_sum(csum) + gauss;
+        gauss = grp_sum<LW>(ln < NV ? (0.5f * Ma - qsm_l) * qacc_l : 0.f);
+        cost = grp_sum<LW>(csum) + gauss;
         grad_l = ln < NV ? Ma - qsm_l - qc : 0.f;
       };
 
-      auto update_search = [&]() {
+      auto update_search = [&](bool act) {
         // H = M + J^T diag(D_active) J changes only when the active set does (mj_solNewton rebuilds on state changes):
-        // otherwise the factor left in LDS by the previous iteration is reused.
+        // otherwise the factor left in LDS by the previous iteration is reused.  With two environments per wave the
+        // rebuild runs for both whenever one of them needs it (the matrix-pipe tile spans the wave; for the other
+        // environment it reproduces the factor it already has).
         bool changed = false;
 #pragma unroll
         for (int rr = 0; rr < RPL; rr++) changed = changed || (dact_cur[rr] != dact_fac[rr]);
+        changed = changed && act;
         unsigned long long q0_ = 0;
         if (PROF) { __builtin_amdgcn_s_waitcnt(0); q0_ = __builtin_amdgcn_s_memtime(); }
+        if (grp_ballot<LW>(changed, hb) != 0ull) st_build++;
         if (__ballot(changed) != 0ull) {
 #pragma unroll
           for (int rr = 0; rr < RPL; rr++) dact_fac[rr] = dact_cur[rr];
-          st_build++;
-          {  // H = M + (D J)^T J on the matrix pipe: v_mfma_f32_32x32x2_f32, two constraint rows per instruction
+          static_assert(NV <= 32, "one 32x32 MFMA tile");
+          if constexpr (EPW == 1) {
+             // H = M + (D J)^T J on the matrix pipe: v_mfma_f32_32x32x2_f32, two constraint rows per instruction
              // (exact fp32 FMA chain; inactive rows carry D = 0).  Lane l feeds A[i = l & 31][k = l >> 5] = D_k J[k][i]
              // and B[k][j = l & 31] = J[k][j]; C/D: col = l & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (l >> 5).
             typedef float f32x16 __attribute__((ext_vector_type(16)));
-            static_assert(NV <= 32, "one 32x32 MFMA tile");
             const int col = ln & 31, half = ln >> 5;
             f32x16 acc;
 #pragma unroll
@@ -1306,6 +1347,31 @@ __global__ __launch_bounds__(64, RPL == 1 ? 4 : 2) void env_kernel(KArgs A) {
               const int row = (v & 3) + 8 * (v >> 2) + 4 * half;
               if (row < NV && col < NV) S.u.H[row][col] = acc[v];
             }
+          } else {
+            // two environments: v_mfma_f32_32x32x1_2b_f32, block b = environment b.  Lane l feeds block l >> 5 with
+            // A[i = l & 31] = D_r J[r][i] and B[j = l & 31] = J[r][j] of its own environment, one constraint row per
+            // instruction; C/D registers 16 b .. 16 b + 15 hold block b: col = l & 31, row = (v & 3) + 8 (v >> 2) + 4 (l >> 5)
+            // -- every lane carries rows of both environments' tiles, so it reads M and writes H of both.
+            typedef float f32x32 __attribute__((ext_vector_type(32)));
+            const int col = wlane & 31, rsel = wlane >> 5;
+            f32x32 acc;
+#pragma unroll
+            for (int v = 0; v < 32; v++) {
+              const int row = (v & 3) + 8 * ((v & 15) >> 2) + 4 * rsel;
+              acc[v] = (row < NV && col < NV) ? SS[v >> 4].M[row < NV ? row : 0][col < NV ? col : 0] : 0.f;
+            }
+            const int ngen_max = max(__builtin_amdgcn_readlane(ngen, 0), __builtin_amdgcn_readlane(ngen, 32));
+            for (int r = 0; r < ngen_max; r++) {
+              const bool ok = r < ngen && col < NV;
+              const float jv = ok ? S.J[ok ? r : 0][ok ? col : 0] : 0.f;
+              const float dv = ok ? S.w.r.rowD[ok ? r : 0] : 0.f;
+              acc = __builtin_amdgcn_mfma_f32_32x32x1f32(jv * dv, jv, acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int v = 0; v < 32; v++) {
+              const int row = (v & 3) + 8 * ((v & 15) >> 2) + 4 * rsel;
+              if (row < NV && col < NV) SS[v >> 4].u.H[row][col] = acc[v];
+            }
           }
           WSYNC();
           if (PROF) { __builtin_amdgcn_s_waitcnt(0); unsigned long long t_ = __builtin_amdgcn_s_memtime(); pacc[10] += t_ - q0_; q0_ = t_; }   // Hessian build
@@ -1316,7 +1382,7 @@ __global__ __launch_bounds__(64, RPL == 1 ? 4 : 2) void env_kernel(KArgs A) {
 #pragma unroll
             for (int k = 0; k < NV; k++) a_row[k] = (ln < NV ? Hr[k] : 0.f) + ((ln == k) ? dd : 0.f);
           }
-          chol_lower<NV>(a_row, dinv, ln);
+          chol_lower<NV, LW>(a_row, dinv, ln, hb);
           WSYNC();
           if (ln < NV) {
 #pragma unroll
@@ -1325,20 +1391,20 @@ __global__ __launch_bounds__(64, RPL == 1 ? 4 : 2) void env_kernel(KArgs A) {
           WSYNC();
         }
         if (PROF) { __builtin_amdgcn_s_waitcnt(0); unsigned long long t_ = __builtin_amdgcn_s_memtime(); pacc[11] += t_ - q0_; q0_ = t_; }   // Cholesky + park
-        const float mg = chol_solve_lds<NV, L::LD>(S.u.H, dinv, grad_l, ln);
+        const float mg = chol_solve_lds<NV, L::LD, LW>(S.u.H, dinv, grad_l, ln, hb);
         if (ln < NV) S.sr[ln] = -mg;
         WSYNC();
         if (PROF) { __builtin_amdgcn_s_waitcnt(0); unsigned long long t_ = __builtin_amdgcn_s_memtime(); pacc[12] += t_ - q0_; }   // triangular solves
       };
 
       update_constraint();
-      float gradnorm = sqrtf(wave_sum(grad_l * grad_l));
+      float gradnorm = sqrtf(grp_sum<LW>(grad_l * grad_l));
       if (A.mode == MODE_DEBUG && A.dbg != nullptr) {
         // dump position/velocity-stage intermediates before the solve
         float* D = A.dbg;
         if (ln == 0) { D[0] = (float)ncon; D[1] = (float)nefc; D[2] = (float)ne; D[3] = (float)nf; D[4] = (float)nl; D[5] = cost; D[6] = gradnorm; D[7] = (float)ngen; }
         if (ln < nbody) { for (int k = 0; k < 3; k++) D[64 + ln * 3 + k] = S.xpos[ln][k]; for (int k = 0; k < 4; k++) D[192 + ln * 4 + k] = S.xquat[ln][k]; }
-        for (int e = ln; e < TRI; e += 64) D[512 + e] = S.M[dm.tri_row[e]][dm.tri_col[e]];
+        for (int e = ln; e < TRI; e += LW) D[512 + e] = S.M[dm.tri_row[e]][dm.tri_col[e]];
         if (ln < NV) { D[1100 + ln] = S.qsm[ln]; for (int q = 0; q < 6; q++) D[1200 + ln * 6 + q] = S.cdof[ln][q]; }
         D[1400 + ln] = (float)rtype[0]; D[1464 + ln] = rD[0]; D[1528 + ln] = raref[0]; D[1592 + ln] = rpos_dbg; D[1656 + ln] = Jaref[0];
         if (ln < ngen) for (int d = 0; d < NV; d++) D[2048 + ln * NV + d] = S.J[ln][d];
@@ -1346,10 +1412,8 @@ __global__ __launch_bounds__(64, RPL == 1 ? 4 : 2) void env_kernel(KArgs A) {
                        D[1900 + ln] = ln < ncon ? (float)S.cgeom[ln] : -1.f;
                        for (int k = 0; k < 3; k++) D[1920 + ln * 3 + k] = (NRM && ln < ncon) ? S.cnrm[NRM ? ln : 0][k] : (k == 2 ? 1.f : 0.f); }
       }
-#pragma nounroll
-      while (niter < maxiter) {
-        if (scale * gradnorm < A.tol32) break;
-        update_search();
+      // one Newton iteration after the search direction is known: exact line search, move, constraint update; false = stop
+      auto newton_iterate = [&]() -> bool {
         unsigned long long q1_ = 0;
         if (PROF) { __builtin_amdgcn_s_waitcnt(0); q1_ = __builtin_amdgcn_s_memtime(); }
         // ---- exact line search on the piecewise-quadratic cost (PrimalSearch)
@@ -1361,9 +1425,9 @@ __global__ __launch_bounds__(64, RPL == 1 ? 4 : 2) void env_kernel(KArgs A) {
           Jv[rr] = rowdot(S.sr, rr);
           q0[rr] = 0.5f * rD[rr] * Jaref[rr] * Jaref[rr]; q1[rr] = rD[rr] * Jaref[rr] * Jv[rr]; q2[rr] = 0.5f * rD[rr] * Jv[rr] * Jv[rr];
         }
-        const float snorm = sqrtf(wave_sum(sr_l * sr_l));
-        if (!(snorm >= 1e-20f)) break;
-        const float qG1 = wave_sum(sr_l * (Ma - qsm_l)), qG2 = wave_sum(0.5f * sr_l * Mv);
+        const float snorm = sqrtf(grp_sum<LW>(sr_l * sr_l));
+        if (!(snorm >= 1e-20f)) return false;
+        const float qG1 = grp_sum<LW>(sr_l * (Ma - qsm_l)), qG2 = grp_sum<LW>(0.5f * sr_l * Mv);
         const float gtol = A.tol32 * dm.ls_tolerance * snorm / scale;
         struct Pnt { float alpha, cost, d0, d1; };
         auto eval = [&](float alpha) -> Pnt {
@@ -1381,7 +1445,7 @@ __global__ __launch_bounds__(64, RPL == 1 ? 4 : 2) void env_kernel(KArgs A) {
               if (x < 0.f) { c0 += q0[rr]; c1 += q1[rr]; c2 += q2[rr]; }
             }
           }
-          float C0 = wave_sum(c0) + gauss, C1 = wave_sum(c1) + qG1, C2 = wave_sum(c2) + qG2;
+          float C0 = grp_sum<LW>(c0) + gauss, C1 = grp_sum<LW>(c1) + qG1, C2 = grp_sum<LW>(c2) + qG2;
           Pnt p;
           p.alpha = alpha;
           p.cost = alpha * alpha * C2 + alpha * C1 + C0;
@@ -1399,7 +1463,7 @@ __global__ __launch_bounds__(64, RPL == 1 ? 4 : 2) void env_kernel(KArgs A) {
           // known in closed form: phi(0) = cost, phi'(0) = g.s, phi''(0) = s'Hs = -g.s (H s = -g on the current active set)
           Pnt p0;
           {
-            const float gs = wave_sum(grad_l * sr_l);
+            const float gs = grp_sum<LW>(grad_l * sr_l);
             p0.alpha = 0.f; p0.cost = cost; p0.d0 = gs; p0.d1 = -gs;
             if (!(p0.d1 > 0.f)) p0.d1 = 1e-15f;
           }
@@ -1456,10 +1520,10 @@ __global__ __launch_bounds__(64, RPL == 1 ? 4 : 2) void env_kernel(KArgs A) {
           }
           lsit_total = lsit;
         }
-        alpha = rfl(alpha);
+        if constexpr (EPW == 1) alpha = rfl(alpha);
         if (PROF) { __builtin_amdgcn_s_waitcnt(0); unsigned long long t_ = __builtin_amdgcn_s_memtime(); pacc[13] += t_ - q1_; q1_ = t_; }   // line search
         st_ls += lsit_total;
-        if (alpha == 0.f) break;
+        if (alpha == 0.f) return false;
         // ---- move
         qacc_l += alpha * sr_l;
         Ma += alpha * Mv;
@@ -1468,11 +1532,20 @@ __global__ __launch_bounds__(64, RPL == 1 ? 4 : 2) void env_kernel(KArgs A) {
         if (ln < NV) S.qacc[ln] = qacc_l;
         const float oldcost = cost;
         update_constraint();
-        gradnorm = sqrtf(wave_sum(grad_l * grad_l));
+        gradnorm = sqrtf(grp_sum<LW>(grad_l * grad_l));
         niter++;
         if (PROF) { __builtin_amdgcn_s_waitcnt(0); unsigned long long t_ = __builtin_amdgcn_s_memtime(); pacc[14] += t_ - q1_; }   // move + constraint update
         const float improvement = scale * (oldcost - cost);
-        if (improvement < A.tol32) break;
+        return !(improvement < A.tol32);
+      };
+      // Environments of one wave iterate together: `act` marks the ones still running, the wave leaves when none is.
+      bool act = true;
+#pragma nounroll
+      while (true) {
+        act = act && niter < maxiter && !(scale * gradnorm < A.tol32);
+        if (__ballot(act) == 0ull) break;
+        update_search(act);
+        if (act) act = newton_iterate();
       }
       st_newton += niter;
       st_rows += nefc;
@@ -1509,7 +1582,7 @@ __global__ __launch_bounds__(64, RPL == 1 ? 4 : 2) void env_kernel(KArgs A) {
           }
           for (int k = 0; k < 6; k++) hit = hit || (wr[k] > 1.0f);
         }
-        if (__ballot(hit) != 0ull) terminated = 1;
+        if (grp_ballot<LW>(hit, hb) != 0ull) terminated = 1;
       }
 
       // =========================================================== mj_implicit (implicitfast) + mj_advance
@@ -1521,7 +1594,7 @@ __global__ __launch_bounds__(64, RPL == 1 ? 4 : 2) void env_kernel(KArgs A) {
 #pragma unroll
           for (int k = 0; k < NV; k++) a_row[k] = (ln < NV ? Mr[k] : 0.f) + ((ln == k) ? hd : 0.f);
         }
-        chol_lower<NV>(a_row, dinv, ln);
+        chol_lower<NV, LW>(a_row, dinv, ln, hb);
         WSYNC();
         if (ln < NV) {
 #pragma unroll
@@ -1529,7 +1602,7 @@ __global__ __launch_bounds__(64, RPL == 1 ? 4 : 2) void env_kernel(KArgs A) {
         }
         WSYNC();
         const float rhs = ln < NV ? qsm_l + S.qcon[ln] : 0.f;
-        const float qa = chol_solve_lds<NV, L::LD>(S.u.H, dinv, rhs, ln);
+        const float qa = chol_solve_lds<NV, L::LD, LW>(S.u.H, dinv, rhs, ln, hb);
         WSYNC();
         if (A.mode != MODE_DEBUG) {
           if (ln < NV) S.qvel[ln] = qv + h * qa;
@@ -1569,7 +1642,7 @@ __global__ __launch_bounds__(64, RPL == 1 ? 4 : 2) void env_kernel(KArgs A) {
       bool nf_ = false;
       if (lane < nq) nf_ = !(fabsf(S.qpos[lane]) < 1e10f);
       if (lane < NV) nf_ = nf_ || !(fabsf(S.qvel[lane]) < 1e10f) || !(fabsf(S.qacc[lane]) < 1e10f);
-      bad = __ballot(nf_) != 0ull;
+      bad = grp_ballot<LW>(nf_, hb) != 0ull;
     }
     if (sim_step == ob.max_sim_step) truncated = 1;
     if (bad) terminated = 1;
@@ -1610,7 +1683,7 @@ __global__ __launch_bounds__(64, RPL == 1 ? 4 : 2) void env_kernel(KArgs A) {
     const bool fill = do_reset;                 // reset fills every stack row with the first frame
     float* so = A.state_out + (size_t)env * ob.state_dim;
     const int sd = ob.stacked_dim, S_ = ob.stack_size;
-    for (int e = lane; e < ob.frame_dim; e += 64) {
+    for (int e = lane; e < ob.frame_dim; e += LW) {
       const int f = ob.el_field[e], idx = ob.el_index[e];
       float val = 0.f;
       switch (f) {
@@ -1680,7 +1753,7 @@ __global__ __launch_bounds__(64, RPL == 1 ? 4 : 2) void env_kernel(KArgs A) {
       const float raw_action = lane < nu ? S.act[lane] : 0.f;
       const float prev_action = (lane < nu && !do_reset) ? rec[lay.s_lastact + lane] : 0.f;   // still the previous step's action
       float dsq = lane < nu ? (raw_action - prev_action) * (raw_action - prev_action) : 0.f;
-      float rmse = sqrtf(wave_sum(dsq) / (float)nu);
+      float rmse = sqrtf(grp_sum<LW>(dsq) / (float)nu);
       if (lane == 0) { inf[0] = rmse; inf[1] = S.sens[7]; inf[2] = S.sens[8]; inf[3] = S.sens[6]; }
       if (lane < nu) { inf[4 + lane] = S.tq[lane]; inf[4 + nu + lane] = raw_action * dm.rec[lane].a_scale; }
       if (lane < dm.ninfo_state) {
