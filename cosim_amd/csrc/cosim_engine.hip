@@ -44,6 +44,7 @@ struct cosim_engine {
   float tol32 = 1e-6f;
   int max_newton = 50;
   int max_ls = 24;
+  int nsub_override = 0;
   // timing
   bool timing = false;
   std::vector<hipEvent_t> ev;  // event pairs (start, stop) of timed launches not yet read back
@@ -53,6 +54,7 @@ struct cosim_engine {
   void (*launch)(cosim_engine*, const KArgs&, int grid, hipStream_t) = nullptr;
   void (*launch_prof)(cosim_engine*, const KArgs&, int grid, hipStream_t) = nullptr;  // diagnostic build (light_v1 flat only)
   void (*launch2)(cosim_engine*, const KArgs&, int grid, hipStream_t) = nullptr;      // two environments per wave (reset / step)
+  void (*launch_prof2)(cosim_engine*, const KArgs&, int grid, hipStream_t) = nullptr;
   int epw = 1;   // environments per wave of the reset / step launches
   int lds_bytes = 0;
 };
@@ -68,6 +70,10 @@ static void launch_prof_t(cosim_engine* e, const KArgs& a, int grid, hipStream_t
 template <int NV, int NB, int GTM>
 static void launch2_t(cosim_engine* e, const KArgs& a, int grid, hipStream_t s) {   // grid = number of envs
   hipLaunchKernelGGL((env_kernel<NV, NB, 2, false, GTM, false, false, 2>), dim3((grid + 1) / 2), dim3(64), 0, s, a);
+}
+template <int NV, int NB, int GTM>
+static void launch_prof2_t(cosim_engine* e, const KArgs& a, int grid, hipStream_t s) {
+  hipLaunchKernelGGL((env_kernel<NV, NB, 2, false, GTM, false, true, 2>), dim3((grid + 1) / 2), dim3(64), 0, s, a);
 }
 template <int NV, int NB, int RPL, int GTM, bool SC>
 static void select_t(cosim_engine* e, bool hf) {
@@ -330,7 +336,7 @@ int cosim_create(const cosim_model_t* model, const float* hull_vert, const int* 
     }
   }
   constexpr int G_LIGHT = GT_SPHERE | GT_CYLINDER | GT_MESH, G_MESH = GT_MESH, G_HUM = GT_BOX | GT_CYLINDER | GT_MESH;
-  if (nv == 18 && nb <= 14 && (gtm & ~G_LIGHT) == 0) { select_t<18, 14, 1, G_LIGHT, false>(e, hf); if (!hf) { e->launch_prof = launch_prof_t<18, 14, 1, G_LIGHT>; e->launch2 = launch2_t<18, 14, G_LIGHT>; } }   // flamingo_light_v1
+  if (nv == 18 && nb <= 14 && (gtm & ~G_LIGHT) == 0) { select_t<18, 14, 1, G_LIGHT, false>(e, hf); if (!hf) { e->launch_prof = launch_prof_t<18, 14, 1, G_LIGHT>; e->launch2 = launch2_t<18, 14, G_LIGHT>; e->launch_prof2 = launch_prof2_t<18, 14, G_LIGHT>; } }   // flamingo_light_v1
   else if (nv == 14 && nb <= 10 && (gtm & ~G_MESH) == 0) select_t<14, 10, 2, G_MESH, true>(e, hf);   // flamingo_p_v3
   else if (nv == 22 && nb <= 18 && (gtm & ~G_MESH) == 0) select_t<22, 18, 2, G_MESH, true>(e, hf);   // w4_p_v2
   else if (nv == 29 && nb <= 26 && (gtm & ~G_HUM) == 0) select_t<29, 26, 2, G_HUM, true>(e, hf);     // humanoid_p_v0
@@ -432,6 +438,7 @@ int cosim_set_param(cosim_engine_t* e, const char* name, const float* host, int 
   else if (n == "solver_tolerance") { e->tol32 = host[0]; return COSIM_OK; }
   else if (n == "max_newton") { e->max_newton = (int)host[0]; return COSIM_OK; }
   else if (n == "max_ls") { e->max_ls = (int)host[0]; return COSIM_OK; }
+  else if (n == "debug_substeps") { e->nsub_override = (int)host[0]; return COSIM_OK; }
   else if (n == "envs_per_wave") {   // 2: the two-environments-per-wave kernel (flat flamingo_light_v1, even env counts); 1: one per wave
     const int w = (int)host[0];
     if (w != 1 && !(w == 2 && e->launch2 && e->n_envs % 2 == 0)) return fail(COSIM_EINVAL, "cosim_set_param: envs_per_wave not available for this model / env count");
@@ -465,7 +472,7 @@ static KArgs base_args(cosim_engine* e) {
   a.hull_vert = e->d_hull_vert; a.hull_adr = e->d_hull_adr; a.hull_nbr = e->d_hull_nbr; a.hfield = e->d_hfield;
   a.pairs = e->d_pairs; a.gext = e->d_gext;
   a.n_envs = e->n_envs; a.seed_lo = (unsigned)e->seed; a.seed_hi = (unsigned)(e->seed >> 32); a.env_id0 = e->env_id0;
-  a.tol32 = e->tol32; a.max_newton = e->max_newton; a.max_ls = e->max_ls;
+  a.tol32 = e->tol32; a.max_newton = e->max_newton; a.max_ls = e->max_ls; a.nsub_override = e->nsub_override;
   return a;
 }
 
@@ -571,7 +578,7 @@ int cosim_debug_forward(cosim_engine_t* e, int env, const char* name, float* hos
   HIP_TRY(hipMemset(e->d_dbg, 0, 8192 * sizeof(float)));
   KArgs a = base_args(e);
   a.mode = MODE_DEBUG; a.dbg = e->d_dbg; a.dbg_env = env;
-  e->launch(e, a, 1, 0);
+  (e->epw == 2 ? e->launch2 : e->launch)(e, a, 1, 0);   // two-per-wave kernel: both groups replay env `env`, same dump twice
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipDeviceSynchronize());
   int n = capacity < 8192 ? capacity : 8192;
@@ -590,12 +597,12 @@ int cosim_profile_step(cosim_engine_t* e, const float* actions_dev, const float*
   KArgs a = base_args(e);
   a.mode = MODE_STEP; a.actions = actions_dev; a.commands = commands_dev; a.state_out = state_out_dev;
   a.terminated = terminated_dev; a.truncated = truncated_dev; a.dbg = e->d_dbg;
-  e->launch_prof(e, a, e->n_envs, 0);
+  (e->epw == 2 ? e->launch_prof2 : e->launch_prof)(e, a, e->n_envs, 0);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipDeviceSynchronize());
   unsigned long long raw[16];
   HIP_TRY(hipMemcpy(raw, e->d_dbg, sizeof raw, hipMemcpyDeviceToHost));
-  for (int i = 0; i < 16; i++) cycles_out16[i] = (double)raw[i] / (double)e->n_envs;
+  for (int i = 0; i < 16; i++) cycles_out16[i] = (double)raw[i] / (double)(e->n_envs / e->epw);   // per wave
   return COSIM_OK;
 }
 

@@ -60,6 +60,7 @@ struct KArgs {
   long long env_id0;
   float tol32;            // fp32 solver tolerance
   int max_newton, max_ls;
+  int nsub_override;      // > 0: physics substeps per control step (diagnostics; 0 = the model's frame_skip)
 };
 
 // ------------------------------------------------------------------------------------------------ wave helpers
@@ -99,6 +100,9 @@ template <int LW>
 __device__ __forceinline__ float grp_sum(float v) {
   if constexpr (LW == 64) return wave_sum(v);
   else {
+    // every lane of the group must end with the same bits (there is no final readlane here): keep the producer of v from
+    // being contracted into the first add (fma(a, b, neighbour) != fma(a', b', own)); the adds themselves commute
+    asm volatile("" : "+v"(v));
     v = row_sum(v);
     return v + __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v), 0x401F));   // partner row of the 32-lane group (xor 16)
   }
@@ -107,6 +111,7 @@ template <int LW>
 __device__ __forceinline__ float grp_min(float v) {
   if constexpr (LW == 64) return wave_min(v);
   else {
+    asm volatile("" : "+v"(v));
     v = fminf(v, dpp<0xB1>(v));
     v = fminf(v, dpp<0x4E>(v));
     v = fminf(v, dpp<0x141>(v));
@@ -413,7 +418,7 @@ __device__ __forceinline__ float impedance(const float* solimp, float pos, float
 // EPW: environments per wave (1: lane l of 64 plays object l; 2: two groups of 32 lanes, RPL rows per lane of the group)
 template <int NV, int NB, int RPL, bool HF, int GTM, bool SC, bool PROF = false, int EPW = 1>
 __global__ __launch_bounds__(64, (RPL == 1 && EPW == 1) ? 4 : 2) void env_kernel(KArgs A) {
-  static_assert(EPW == 1 || (EPW == 2 && !HF && !SC && !PROF && NV <= 32 && NB <= 32), "two environments per wave: flat ground, no pairs");
+  static_assert(EPW == 1 || (EPW == 2 && !HF && !SC && NV <= 32 && NB <= 32), "two environments per wave: flat ground, no pairs");
   constexpr bool NRM = HF || SC;
   constexpr int LW = 64 / EPW;
   using L = EnvLds<NV, NB, RPL, NRM, LW>;
@@ -519,7 +524,7 @@ __global__ __launch_bounds__(64, (RPL == 1 && EPW == 1) ? 4 : 2) void env_kernel
       WSYNC();
     }
 
-    const int nsub = A.mode == MODE_DEBUG ? 1 : dm.frame_skip;
+    const int nsub = A.mode == MODE_DEBUG ? 1 : (A.nsub_override > 0 ? A.nsub_override : dm.frame_skip);
 #pragma nounroll
     for (int sub = 0; sub < nsub; sub++) {
       int ln = lane;
@@ -1521,6 +1526,7 @@ __global__ __launch_bounds__(64, (RPL == 1 && EPW == 1) ? 4 : 2) void env_kernel
           lsit_total = lsit;
         }
         if constexpr (EPW == 1) alpha = rfl(alpha);
+        if constexpr (EPW == 2) alpha = grp_bcast<LW>(alpha, 0, hb);
         if (PROF) { __builtin_amdgcn_s_waitcnt(0); unsigned long long t_ = __builtin_amdgcn_s_memtime(); pacc[13] += t_ - q1_; q1_ = t_; }   // line search
         st_ls += lsit_total;
         if (alpha == 0.f) return false;
@@ -1543,7 +1549,9 @@ __global__ __launch_bounds__(64, (RPL == 1 && EPW == 1) ? 4 : 2) void env_kernel
 #pragma nounroll
       while (true) {
         act = act && niter < maxiter && !(scale * gradnorm < A.tol32);
-        if (__ballot(act) == 0ull) break;
+        const bool any = __ballot(act) != 0ull;
+        if (!any) break;
+        if constexpr (EPW == 1) act = any;   // one environment: wave-uniform, keeps the body a scalar branch
         update_search(act);
         if (act) act = newton_iterate();
       }
@@ -1764,7 +1772,7 @@ __global__ __launch_bounds__(64, (RPL == 1 && EPW == 1) ? 4 : 2) void env_kernel
     if (lane == 0) { A.terminated[env] = (uint8_t)terminated; A.truncated[env] = (uint8_t)truncated; }
   }
   STAMP(9);   // observation build + info
-  if (PROF && A.dbg != nullptr && lane == 0)
+  if (PROF && A.dbg != nullptr && wlane == 0)
     for (int i = 0; i < 16; i++) atomicAdd(reinterpret_cast<unsigned long long*>(A.dbg) + i, pacc[i]);
   if (lane < nq) rec[lay.s_qpos + lane] = S.qpos[lane];
   if (lane < NV) { rec[lay.s_qvel + lane] = S.qvel[lane]; rec[lay.s_warm + lane] = S.qacc[lane]; }
