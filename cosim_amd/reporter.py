@@ -1,0 +1,64 @@
+"""Fleet reporter: what the reference's ``Reporter`` distils from the ``info`` stream (core/reporter.py:210-218 write_info,
+:257 dt, :380-382 set_points vs state, :429-442 torque / action_diff_RMSE, :506-508 command tracking), reduced over N envs.
+
+``write_info(info)`` takes the batched ``info`` dict of ``BatchedEnv.step`` and keeps sufficient statistics on the device
+(``distributed.MetricsAccumulator``: one small all-reduce across GPUs when ``summary()`` is called); ``trace_env`` keeps
+the full per-step series of one env as plain numpy / floats — the dict stream the reference's single-env ``Reporter``
+consumes, so its PDF code can be fed from it unchanged.
+"""
+from __future__ import annotations
+
+import json
+from typing import Optional
+
+import numpy as np
+
+from .distributed import MetricsAccumulator
+
+
+class FleetReporter:
+    def __init__(self, env, trace_env: Optional[int] = None):
+        self.env, self.trace_env = env, trace_env
+        nu, cd = env.action_dim, env.command_dim
+        self.names = (["action_diff_RMSE", "lin_vel_x", "lin_vel_y", "ang_vel_yaw"] + [f"abs_torque_{i}" for i in range(nu)] +
+                      [f"tracking_err_{i}" for i in range(min(cd, 3))])
+        self.acc = MetricsAccumulator(self.names, device=env.device)
+        self.trace = []
+        self.steps = 0
+        self.episodes_ended = 0
+
+    def write_info(self, info: dict):
+        t = self.env.torch
+        cols = [info["action_diff_RMSE"], info["lin_vel_x"], info["lin_vel_y"], info["ang_vel_yaw"]]
+        cols += [info["torque"][:, i].abs() for i in range(self.env.action_dim)]
+        # command tracking (reporter.py:506-508): applied command 0,1 vs base linear velocity, 2 vs yaw rate
+        meas = [info["lin_vel_x"], info["lin_vel_y"], info["ang_vel_yaw"]]
+        for i in range(min(self.env.command_dim, 3)):
+            cols.append((info[f"user_command_{i}"] - meas[i]).abs())
+        self.acc.update(t.stack([c.to(t.float32) for c in cols], dim=1))
+        self.steps += 1
+        if self.trace_env is not None:
+            i = self.trace_env
+            row = {}
+            for k, v in info.items():
+                if hasattr(v, "shape") and len(v.shape) >= 1 and v.shape[0] == self.env.num_envs:
+                    x = v[i].detach().cpu().numpy()
+                    row[k] = x.astype(np.float64) if x.ndim else float(x)
+                else:
+                    row[k] = v
+            self.trace.append(row)
+
+    def note_done(self, terminated, truncated):
+        self.episodes_ended += int((terminated | truncated).sum().item())
+
+    def summary(self) -> dict:
+        return {"control_steps": self.steps, "envs": self.env.num_envs, "episodes_ended": self.episodes_ended, "metrics": self.acc.reduce()}
+
+    def save(self, path: str):
+        out = self.summary()
+        if self.trace:
+            out["trace_env"] = self.trace_env
+            out["trace"] = {k: np.asarray([r[k] for r in self.trace]).tolist() for k in self.trace[0]}
+        with open(path, "w") as f:
+            json.dump(out, f)
+        return out

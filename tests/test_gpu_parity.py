@@ -577,3 +577,17 @@ def test_stairs_class_heightfield_is_refused_loudly():
     from cosim_amd.config import PARITY_RANDOM, make_config
     with pytest.raises((ValueError, RuntimeError), match="stairs"):
         BatchedEnv(make_config("flamingo_light_v1", terrain="stairs_up_easy", random=PARITY_RANDOM), num_envs=2)
+
+
+def test_cli_rollout_with_onnx_policy_on_device(tmp_path):
+    """policy (ONNX file read here) -> step -> fleet report, everything resident on the GPU."""
+    import json
+    from cosim_amd import cli
+    rep = tmp_path / "report.json"
+    assert cli.main(["--env", "flamingo_light_v1", "--num-envs", "64", "--steps", "60", "--policy", "random-mlp", "--report", str(rep),
+                     "--trace-env", "3", "--push-at", "20", "--command", "0.5", "0", "0", "0"]) == 0
+    out = json.loads(rep.read_text())
+    assert out["control_steps"] == 60 and out["envs"] == 64 and out["metrics"]["lin_vel_x"]["count"] == 64 * 60
+    assert len(out["trace"]["torque"]) == 60 and len(out["trace"]["torque"][0]) == 4
+    assert {"dt", "action", "action_diff_RMSE", "torque", "lin_vel_x", "set_points", "state", "user_command_0"} <= set(out["trace"])
+    assert np.isfinite([v["mean"] for v in out["metrics"].values()]).all()
