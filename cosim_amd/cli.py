@@ -35,6 +35,7 @@ def main(argv=None) -> int:
     ap.add_argument("--push", type=float, nargs=3, default=[0.5, 0.0, 0.0])
     ap.add_argument("--report", default="", help="write the fleet report (JSON) here")
     ap.add_argument("--trace-env", type=int, default=-1, help="also keep the per-step info series of this local env")
+    ap.add_argument("--graph", action="store_true", help="capture policy -> step -> report in a HIP graph and replay it (ONNX policies)")
     ap.add_argument("--backend", default="nccl")
     args = ap.parse_args(argv)
 
@@ -74,7 +75,7 @@ def main(argv=None) -> int:
             run.deactivate_push_event()
     torch.cuda.synchronize(env.device)
     t0 = time.perf_counter()
-    n = run.test(max_steps=args.steps, on_step=on_step)
+    n = run.test_graphed(args.steps) if args.graph else run.test(max_steps=args.steps, on_step=on_step)
     torch.cuda.synchronize(env.device)
     dt = time.perf_counter() - t0
     out = rep.save(args.report) if (args.report and rank == 0) else rep.summary()

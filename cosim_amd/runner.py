@@ -83,3 +83,43 @@ class Runner:
             if not env.auto_reset:
                 done_all = bool((terminated | truncated).all().item())
         return steps
+
+    def test_graphed(self, max_steps: int, warmup: int = 3) -> int:
+        """The same loop with one control step (policy -> step -> reporter update) captured in a HIP graph and replayed:
+        the per-step host work of ~40 small launches collapses into one graph launch.  Needs an auto-reset env, a policy
+        whose ``get_action`` is pure device work on persistent tensors (``policy.MLPPolicy``; not ``SinusoidPolicy``, whose
+        clock lives on the host) and a reporter that only updates device buffers (``reporter.FleetReporter`` without
+        ``trace_env``).  The user command and push flag are read from persistent device tensors, so ``update_command``
+        between replays still takes effect; a push is applied outside the graph."""
+        env, t = self.env, self.env.torch
+        if not env.auto_reset:
+            raise ValueError("test_graphed needs auto_reset=True (no per-step host check of the done flags)")
+        state, _ = env.reset()
+        env.receive_user_command(self.user_command)
+        action = t.zeros((env.num_envs, env.action_dim), dtype=t.float32, device=env.device)
+
+        def one_step():
+            action.copy_(self.policy.get_action(env.state))
+            _, _, _, info = env.step(action)
+            if self.reporter is not None:
+                self.reporter.write_info(info)
+        side = t.cuda.Stream(device=env.device)
+        side.wait_stream(t.cuda.current_stream(env.device))
+        with t.cuda.stream(side):
+            for _ in range(warmup):
+                one_step()
+        t.cuda.current_stream(env.device).wait_stream(side)
+        t.cuda.synchronize(env.device)
+        graph = t.cuda.CUDAGraph()
+        with t.cuda.graph(graph):
+            one_step()
+        steps = warmup + 1
+        while steps < max_steps and not self._stop:
+            env.receive_user_command(self.user_command)
+            if self._push_event:
+                env.event("push", self._push_vel)
+            graph.replay()
+            steps += 1
+        if self.reporter is not None and hasattr(self.reporter, "steps"):
+            self.reporter.steps = steps          # write_info ran once per replay on the device, once in Python
+        return steps

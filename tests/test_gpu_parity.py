@@ -591,3 +591,33 @@ def test_cli_rollout_with_onnx_policy_on_device(tmp_path):
     assert len(out["trace"]["torque"]) == 60 and len(out["trace"]["torque"][0]) == 4
     assert {"dt", "action", "action_diff_RMSE", "torque", "lin_vel_x", "set_points", "state", "user_command_0"} <= set(out["trace"])
     assert np.isfinite([v["mean"] for v in out["metrics"].values()]).all()
+
+
+def test_graph_captured_rollout_equals_eager(tmp_path):
+    """One control step (ONNX policy -> cosim_step -> fleet report) captured in a HIP graph and replayed gives the bits of the
+    eager loop: the engine's launch is capturable on the caller's stream (no hidden host work in cosim_step)."""
+    import torch
+    from cosim_amd.batched_env import BatchedEnv
+    from cosim_amd.config import make_config
+    from cosim_amd.policy import MLPPolicy, write_random_mlp
+    from cosim_amd.reporter import FleetReporter
+    from cosim_amd.runner import Runner
+    cfg = make_config("flamingo_light_v1", num_envs=64, seed=7)
+    path = str(tmp_path / "actor.onnx")
+    outs = []
+    for graphed in (False, True):
+        env = BatchedEnv(cfg, num_envs=64, seed=7, auto_reset=True)
+        if not graphed:
+            write_random_mlp(path, env.state_dim, env.action_dim, hidden=(64, 64), seed=5)
+        rep = FleetReporter(env)
+        run = Runner(env, MLPPolicy(path, device=env.device), reporter=rep)
+        run.update_command(0, 0.5)
+        n = run.test_graphed(40) if graphed else run.test(max_steps=40)
+        assert n == 40
+        torch.cuda.synchronize()
+        outs.append((env.state.clone(), env.get_data().qpos.clone(), rep.summary()))
+        env.close()
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    m0, m1 = outs[0][2]["metrics"], outs[1][2]["metrics"]
+    assert m0["lin_vel_x"]["count"] == m1["lin_vel_x"]["count"] == 64 * 40
+    assert m0["abs_torque_0"]["mean"] == pytest.approx(m1["abs_torque_0"]["mean"], rel=1e-12)
