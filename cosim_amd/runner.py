@@ -113,7 +113,7 @@ class Runner:
         graph = t.cuda.CUDAGraph()
         with t.cuda.graph(graph):
             one_step()
-        steps = warmup + 1
+        steps = warmup                            # capturing records the step, it does not run it
         while steps < max_steps and not self._stop:
             env.receive_user_command(self.user_command)
             if self._push_event:
