@@ -163,20 +163,32 @@ def main():
     n = args.envs_per_gpu or n_default
     env_id0 = rank * n
 
-    cfg = make_config(robot, terrain=terrain, num_envs=n, seed=1234, height_map=hmap)
-    env = BatchedEnv(cfg, num_envs=n, device=local, seed=1234, auto_reset=True, env_id0=env_id0, gain_noise=0.1)
+    S = max(1, args.streams)
+    if n % S:
+        raise SystemExit(f"--streams {S} must divide the envs per GPU ({n})")
+    ns = n // S
+    cfg = make_config(robot, terrain=terrain, num_envs=ns, seed=1234, height_map=hmap)
+    # S = 1: one launch per fleet step.  S > 1: the fleet as S independent shards (own engine handle, own HIP stream, global env
+    # ids unchanged), so a shard's next control step fills the tail of the others' launches.
+    envs = [BatchedEnv(cfg, num_envs=ns, device=local, seed=1234, auto_reset=True, env_id0=env_id0 + i * ns, gain_noise=0.1) for i in range(S)]
+    env = envs[0]
+    streams = [torch.cuda.current_stream(env.device)] if S == 1 else [torch.cuda.Stream(device=env.device) for _ in range(S)]
     nu = env.action_dim
     total_steps = args.warmup + args.steps
-    actions = synthetic_actions(n, env_id0, total_steps, nu, env.device)
-    env.receive_user_command(np.array([0.5, 0.0, 0.0, 0.0], dtype=np.float32))
+    actions = [synthetic_actions(ns, env_id0 + i * ns, total_steps, nu, env.device) for i in range(S)]
     metrics = MetricsAccumulator(["action_diff_RMSE", "lin_vel_x", "lin_vel_y", "ang_vel_yaw"], device=env.device)
-    env.reset()
-    for t in range(args.warmup):
-        env.step(actions[t])
+    for i, e in enumerate(envs):
+        with torch.cuda.stream(streams[i]):
+            e.receive_user_command(np.array([0.5, 0.0, 0.0, 0.0], dtype=np.float32))
+            e.reset()
+            for t in range(args.warmup):
+                e.step(actions[i][t])
+    torch.cuda.synchronize()
     metrics.update(env.info_buf[:, :4])   # warm-up of the torch reduction kernels (first use loads code objects: ~100 ms)
     metrics.reduce()
     metrics.buf.zero_()
-    env.engine.set_timing(True)
+    for e in envs:
+        e.engine.set_timing(True)
 
     def sync():
         torch.cuda.synchronize()
@@ -187,16 +199,23 @@ def main():
     sync()
     t0 = time.perf_counter()
     for t in range(args.warmup, total_steps):
-        state, term, trunc, info = env.step(actions[t])
-        if (t & 63) == 0:
-            metrics.update(env.info_buf[:, :4])        # reporter statistics, sampled off the critical path
+        for i, e in enumerate(envs):
+            with torch.cuda.stream(streams[i]):
+                state, term, trunc, info = e.step(actions[i][t])
+                if (t & 63) == 0:
+                    metrics.update(e.info_buf[:, :4])  # reporter statistics, sampled off the critical path
+    torch.cuda.synchronize()
     fleet = metrics.reduce()                            # the one collective: RCCL all-reduce of (count, sum, sum^2)
     sync()
     dt = time.perf_counter() - t0
-    kernel_ms, launches = env.engine.kernel_time()
-    env.engine.set_timing(False)
-    finite = bool(torch.isfinite(state).all().item())
-    st = env.solver_stats()
+    kt = [e.engine.kernel_time() for e in envs]
+    launches = sum(k[1] for k in kt)
+    kernel_ms = sum(k[0] * k[1] for k in kt) / max(1, launches)
+    for e in envs:
+        e.engine.set_timing(False)
+    finite = all(bool(torch.isfinite(e.state).all().item()) for e in envs)
+    sts = [e.solver_stats() for e in envs]
+    st = {k: sum(x[k] for x in sts) for k in sts[0]}
     nsub = max(1, (st["step_count"] - n) * 4)    # the reset launch also bumps the step counter once per env
 
     tmax = torch.tensor([dt], dtype=torch.float64, device=env.device)
@@ -207,7 +226,7 @@ def main():
     if rank == 0:
         value = world * n * args.steps / dt
         balg = b_alg(env.nq, env.nv, nu, env.state_dim)
-        achieved = balg * n / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
+        achieved = balg * ns / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0   # one launch processes ns envs
         line = {
             "metric": f"env-steps/sec (whole node), {robot} xN envs", "value": value, "unit": "env-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
@@ -215,6 +234,7 @@ def main():
             "config": {"workload": f"{robot} x {n} envs per GPU, {terrain} terrain, precision medium (4 x 5 ms substeps), "
                                    "GUI-default domain randomisation + sensor noise low, sinusoid actions, auto-reset",
                        "envs_per_gpu": n, "global_envs": world * n, "substeps_per_s": value * 4, "parallelism": f"shard{world}",
+                       "streams_per_gpu": S, "envs_per_launch": ns,
                        "finite": finite, "fleet_action_diff_RMSE": fleet["action_diff_RMSE"]["mean"],
                        "solver_per_substep": {"rows": st["rows"] / nsub, "newton_iters": st["newton_iters"] / nsub,
                                               "ls_evals": st["ls_evals"] / nsub, "factorisations": st["factorisations"] / nsub},
@@ -231,7 +251,8 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
-    env.close()
+    for e in envs:
+        e.close()
 
 
 if __name__ == "__main__":

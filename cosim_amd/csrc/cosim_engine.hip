@@ -503,7 +503,7 @@ int cosim_step(cosim_engine_t* e, const float* actions_dev, const float* command
   int slot = -1;
   if (e->timing) {
     if (e->ev_used + 2 > (int)e->ev.size()) {
-      if (e->ev.size() >= 16384) { int rc2 = drain_events(e); if (rc2) return rc2; }
+      if (e->ev.size() >= 4096) { int rc2 = drain_events(e); if (rc2) return rc2; }
       else for (int i = 0; i < 2; i++) { hipEvent_t x; HIP_TRY(hipEventCreate(&x)); e->ev.push_back(x); }
     }
     slot = e->ev_used;
@@ -612,6 +612,8 @@ int cosim_set_timing(cosim_engine_t* e, int enabled) {
   int rc = drain_events(e);
   if (rc) return rc;
   e->timing = enabled != 0;
+  if (e->timing)   // event pool up front: creating events inside a timed loop costs host time per launch
+    while (e->ev.size() < 4096) { hipEvent_t x; HIP_TRY(hipEventCreate(&x)); e->ev.push_back(x); }
   e->t_accum_ms = 0.0;
   e->t_launches = 0;
   return COSIM_OK;
