@@ -621,3 +621,52 @@ def test_graph_captured_rollout_equals_eager(tmp_path):
     m0, m1 = outs[0][2]["metrics"], outs[1][2]["metrics"]
     assert m0["lin_vel_x"]["count"] == m1["lin_vel_x"]["count"] == 64 * 40
     assert m0["abs_torque_0"]["mean"] == pytest.approx(m1["abs_torque_0"]["mean"], rel=1e-12)
+
+
+def test_non_finite_state_resets_only_that_env(parity):
+    """mj_checkPos / mj_checkVel / mj_checkAcc (mj_step resets the data on a bad state): a NaN in one env ends and restarts
+    that env inside the step, is counted, and leaves its neighbours bit-identical to a run without the fault."""
+    from cosim_amd.batched_env import BatchedEnv
+    from cosim_amd.config import PARITY_RANDOM, make_config
+    torch = parity["torch"]
+    cfg = make_config("flamingo_light_v1", random=PARITY_RANDOM)
+    envs = [BatchedEnv(cfg, num_envs=5, auto_reset=True) for _ in range(2)]
+    for e in envs:
+        e.reset()
+    a = torch.zeros((5, 4), device=envs[0].device)
+    for t in range(5):
+        for e in envs:
+            e.step(a)
+    d = envs[1].get_data()
+    qv = d.qvel.clone()
+    qv[2, 7] = float("nan")
+    envs[1].set_state(qvel=qv.cpu().numpy())
+    s0, t0, _, _ = envs[0].step(a)
+    s1, t1, _, _ = envs[1].step(a)
+    assert t1.cpu().numpy().tolist() == [0, 0, 1, 0, 0] and int(t0.sum()) == 0
+    keep = [0, 1, 3, 4]
+    assert torch.equal(s0[keep], s1[keep]) and bool(torch.isfinite(s1).all())
+    assert envs[1].solver_stats()["nan_resets"] == 1 and envs[0].solver_stats()["nan_resets"] == 0
+    q1 = envs[1].get_data().qpos
+    assert float(q1[2, 2]) == pytest.approx(0.13)                    # back at the initial height
+    for e in envs:
+        e.close()
+
+
+@pytest.mark.parametrize("n", [1, 3, 65])
+def test_ragged_env_counts_and_saturated_actions(n):
+    """Env counts that do not fill a wave group / are odd, driven with actions far outside [-1, 1] (torque clip, ctrlrange)."""
+    import torch
+    from cosim_amd.batched_env import BatchedEnv
+    from cosim_amd.config import make_config
+    env = BatchedEnv(make_config("flamingo_light_v1", num_envs=n, seed=3), num_envs=n, seed=3, auto_reset=True)
+    s, _ = env.reset()
+    assert s.shape == (n, env.state_dim)
+    big = torch.full((n, 4), 50.0, device=env.device)
+    for t in range(30):
+        s, term, trunc, info = env.step(big if t % 2 else -big)
+    assert bool(torch.isfinite(s).all()) and float(info["torque"].abs().max()) <= 60.0 + 1e-3
+    assert env.solver_stats()["nan_resets"] == 0
+    with pytest.raises(ValueError, match="Action dimension mismatch"):
+        env.step(torch.zeros((n + 1, 4), device=env.device))
+    env.close()
