@@ -127,8 +127,8 @@ def pmc_traffic(workload):
     return {"traffic": vals["FETCH_SIZE"] + vals["WRITE_SIZE"],
             "traffic_note": f"bytes per launch, {os.path.basename(files[-1])}: FETCH_SIZE {vals['FETCH_SIZE']:.3g} B (dword-per-lane "
                             "reads, taken at face value: the guide's x2 gfx950 correction is calibrated for 16-B/lane streaming "
-                            f"reads only) + WRITE_SIZE {vals['WRITE_SIZE']:.3g} B (mostly write-back of the 72 B/lane register-"
-                            "spill scratch)"}
+                            f"reads only) + WRITE_SIZE {vals['WRITE_SIZE']:.3g} B (mostly write-back of the register-spill "
+                            "scratch, ~76 B/lane x 262144 lanes)"}
 
 
 def main():
