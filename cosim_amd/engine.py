@@ -156,6 +156,10 @@ def make_obs_config(config: dict, obs_to_dim: Dict[str, int], control_freq: floa
     c.auto_reset = int(auto_reset)
     hm = ob.get("height_map")
     if hm is not None:
+        if config["env"]["terrain"] == "flat" and ("height_map" in list(ob["stacked_obs_order"]) + list(ob["non_stacked_obs_order"])):
+            # the reference samples the map with mj_rayHfield on the ground geom (utils/mujoco_utils.py:169), which is an error
+            # on the plane that terrain "flat" turns the ground into (xml_manager.py:24-28)
+            raise ValueError("the height_map observation needs a heightfield terrain (mj_rayHfield rejects the plane of terrain 'flat')")
         c.hm_res_x, c.hm_res_y = int(hm["res_x"]), int(hm["res_y"])
         c.hm_size_x, c.hm_size_y = float(hm["size_x"]), float(hm["size_y"])
     return c

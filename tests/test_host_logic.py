@@ -164,3 +164,13 @@ def test_mujoco_crosscheck_is_opportunistic(tmp_path):
     r = subprocess.run([sys.executable, os.path.join(os.path.dirname(__file__), "..", "tools", "crosscheck_mujoco.py"), "--steps", "5"],
                        capture_output=True, text=True, timeout=120)
     assert r.returncode == 77 and "SKIPPED" in r.stdout
+
+
+def test_height_map_on_flat_terrain_is_refused():
+    """mj_rayHfield (reference utils/mujoco_utils.py:169) needs an hfield ground; terrain 'flat' makes it a plane."""
+    cfg = make_config("w4_p_v2", terrain="flat", height_map=True)
+    from cosim_amd.robots import obs_to_dim
+    with pytest.raises(ValueError, match="heightfield terrain"):
+        make_obs_config(cfg, obs_to_dim("w4_p_v2", cfg), 50.0, True)
+    ok = make_config("w4_p_v2", terrain="rocky_easy", height_map=True)
+    make_obs_config(ok, obs_to_dim("w4_p_v2", ok), 50.0, True)
