@@ -35,6 +35,7 @@ HBM_PEAK_GBS = 8000.0
 # configuration the metric is quoted on; the others are the remaining BASELINE configs, selectable for DESIGN.md numbers.
 WORKLOADS = {
     "light_flat": ("flamingo_light_v1", "flat", False, 4096),
+    "light_rocky": ("flamingo_light_v1", "rocky_hard", False, 4096),
     "w4_rocky": ("w4_p_v2", "rocky_hard", True, 4096),            # configs[2]
     "p_v3_flat": ("flamingo_p_v3", "flat", False, 4096),          # configs[3] per-GPU shard (flat; its terrain is not named)
     "humanoid_flat": ("humanoid_p_v0", "flat", False, 1024),      # configs[4] per-GPU shard on flat (stairs need more rows)

@@ -99,6 +99,7 @@ static int build_dev_model(cosim_engine* e) {
   if (m.ground_type != CS_GEOM_PLANE && (m.hfield_nrow < 2 || m.hfield_ncol < 2)) return fail(COSIM_EINVAL, "heightfield ground without elevation data");
   if (m.nbody > 32 || m.nv > 32 || m.ngeom > 32 || m.nq > 64) return fail(COSIM_EINVAL, "model exceeds the per-lane record capacity");
   if (m.neq > MAXEQ) return fail(COSIM_EINVAL, "too many equalities");
+  if (m.ngeom > 24 || m.nu > m.nv - 6 || m.nq != m.nv + 1) return fail(COSIM_EINVAL, "model exceeds the per-env LDS tables (geoms <= 24, nu <= nv - 6, one free joint)");
   int maxdepth = 0;
   // dof ancestor masks
   unsigned anc[MAXD];

@@ -203,6 +203,7 @@ struct EnvLds {
   static constexpr int MC = ROWS <= 64 ? 12 : 16;  // contact slots (4 pyramid rows each)
   static constexpr int NGEN = 3 * MAXEQ / 2 + 4 * MC;  // dense rows: 2 connect equalities (6 rows) + contacts
   static constexpr int NLIM = ROWS / 8;
+  static constexpr int NUMAX = NV - 6;   // actuators: at most one per hinge dof (the free joint's six dofs carry none)
   float qpos[CS_MAXQ], qvel[NV], qacc[NV], qact[NV], qsm[NV], qcon[NV], sr[NV], dofD[NV];
   float xpos[NB][3], xquat[NB][4], xanc[NB][3], xax[NB][3];
   float cdof[NV][6];
@@ -220,8 +221,8 @@ struct EnvLds {
   int cgeom[MC];   // geom2 | (geom1 + 1) << 8; geom1 + 1 == 0: the ground
   int lim_body[NLIM];
   float lim_sign[NLIM], lim_dist[NLIM];
-  float p_mass[NB], p_binvw[NB], p_dinvw[NV], p_floss[NV], p_gmu[32];
-  float act[MAXU], tq[MAXU], cmd[CS_MAXCMD + 2];
+  float p_mass[NB], p_binvw[NB], p_dinvw[NV], p_floss[NV], p_gmu[24];   // collision geoms: at most 22 (humanoid_p_v0)
+  float act[NUMAX], tq[NUMAX], cmd[CS_MAXCMD + 2];
   float sens[10];   // framequat[4], gyro[3], velocimeter[3] of the last substep's forward pass
   float com[3];
   int ncon_ctr;
@@ -484,7 +485,7 @@ __global__ __launch_bounds__(64, (RPL == 1 && EPW == 1) ? 4 : 2) void env_kernel
 
   // sensor values of the last forward pass (uniform across the wave)
   // (sensor values of the last forward pass, the raw action and the applied torque live in LDS: S.sens, S.act, S.tq)
-  if (lane < MAXU) { S.act[lane] = 0.f; S.tq[lane] = 0.f; }
+  if (lane < L::NUMAX) { S.act[lane] = 0.f; S.tq[lane] = 0.f; }
   if (lane < 10) S.sens[lane] = lane == 0 ? 1.f : 0.f;
   int terminated = 0, truncated = 0, bad = 0;
   int st_newton = 0, st_ls = 0, st_build = 0, st_rows = 0;  // solver statistics of this control step
@@ -1675,7 +1676,7 @@ __global__ __launch_bounds__(64, (RPL == 1 && EPW == 1) ? 4 : 2) void env_kernel
       qnorm(sq);
       if (lane == 0) { for (int k = 0; k < 4; k++) S.sens[k] = sq[k]; for (int k = 4; k < 10; k++) S.sens[k] = 0.f; }
     }
-    if (lane < MAXU) { S.act[lane] = 0.f; S.tq[lane] = 0.f; }
+    if (lane < L::NUMAX) { S.act[lane] = 0.f; S.tq[lane] = 0.f; }
     has_prev = 0;
     sim_step = 0;
   }
