@@ -33,7 +33,7 @@ __device__ __forceinline__ real mpr_dot(const real* a, const real* b) { return a
 __device__ __forceinline__ void mpr_cross(real* r, const real* a, const real* b) {
   r[0] = a[1] * b[2] - a[2] * b[1]; r[1] = a[2] * b[0] - a[0] * b[2]; r[2] = a[0] * b[1] - a[1] * b[0];
 }
-struct MprSup { real v[3], v1[3]; };  // Minkowski-difference support point v = s1(dir) - s2(-dir) and its s1 part
+struct MprSup { real v[3]; float v1[3]; };  // Minkowski-difference support point v = s1(dir) - s2(-dir) (exact in fp64) and its fp32 s1 part
 
 __device__ __forceinline__ bool mpr_zero(real x) { return fabs(x) < MPR_EPS; }
 __device__ __forceinline__ bool mpr_eq(real a, real b) {
@@ -97,7 +97,7 @@ struct MprPair {
     float v1[3], v2[3];
     cobj_support<GTM, COOP>(a, hull, fd, v1, ln);
     cobj_support<GTM, COOP>(b, hull, nd, v2, ln);
-    for (int k = 0; k < 3; k++) { s.v1[k] = (real)v1[k]; s.v[k] = (real)v1[k] - (real)v2[k]; }
+    for (int k = 0; k < 3; k++) { s.v1[k] = v1[k]; s.v[k] = (real)v1[k] - (real)v2[k]; }
   }
 };
 
@@ -166,7 +166,7 @@ __device__ __forceinline__ bool mpr_penetration(const SUP& sup, const float* c1,
   if (mpr_zero(mpr_dot(dir, dir))) {
     if (mpr_vzero(p1.v)) return false;                    // touching: depth 0, no direction -> MuJoCo drops it
     // origin on the v0-v1 segment (findPenetrSegment): v2 of the support = v1 - v
-    pos[0] = p1.v1[0] - 0.5 * p1.v[0]; pos[1] = p1.v1[1] - 0.5 * p1.v[1]; pos[2] = p1.v1[2] - 0.5 * p1.v[2];
+    pos[0] = (real)p1.v1[0] - 0.5 * p1.v[0]; pos[1] = (real)p1.v1[1] - 0.5 * p1.v[1]; pos[2] = (real)p1.v1[2] - 0.5 * p1.v[2];
     dir_out[0] = p1.v[0]; dir_out[1] = p1.v[1]; dir_out[2] = p1.v[2];
     depth = mpr_normalize(dir_out);
     depth_out = (float)depth;
@@ -255,7 +255,7 @@ __device__ __forceinline__ bool mpr_penetration(const SUP& sup, const float* c1,
     const real inv = 1. / sum;
     for (int k = 0; k < 3; k++) {
       // p1' = sum b_i v1_i, p2' = sum b_i v2_i with v2_i = v1_i - v_i;  pos = (p1' + p2') / 2
-      const real s1 = b0 * (real)c1[k] + b1 * p1.v1[k] + b2 * p2.v1[k] + b3 * p3.v1[k];
+      const real s1 = b0 * (real)c1[k] + b1 * (real)p1.v1[k] + b2 * (real)p2.v1[k] + b3 * (real)p3.v1[k];
       const real sv = b0 * v0[k] + b1 * p1.v[k] + b2 * p2.v[k] + b3 * p3.v[k];
       pos[k] = (s1 - 0.5 * sv) * inv;
     }
@@ -292,7 +292,7 @@ struct MprPrismGeom {
     float v1[3], v2[3];
     prism_support(P, fd, v1);
     cobj_support<GTM, COOP>(g, hull, nd, v2, ln);
-    for (int k = 0; k < 3; k++) { s.v1[k] = (real)v1[k]; s.v[k] = (real)v1[k] - (real)v2[k]; }
+    for (int k = 0; k < 3; k++) { s.v1[k] = v1[k]; s.v[k] = (real)v1[k] - (real)v2[k]; }
   }
 };
 
