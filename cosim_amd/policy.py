@@ -170,9 +170,13 @@ class OnnxGraph:
             if op == "Gemm":
                 A = x[0].transpose(-1, -2) if a.get("transA", 0) else x[0]
                 B = x[1].transpose(-1, -2) if a.get("transB", 0) else x[1]
-                y = a.get("alpha", 1.0) * (A @ B)
-                if len(x) > 2 and x[2] is not None:
-                    y = y + a.get("beta", 1.0) * x[2]
+                al, be = a.get("alpha", 1.0), a.get("beta", 1.0)
+                if len(x) > 2 and x[2] is not None and A.dim() == 2 and x[2].dim() <= 2:
+                    y = t.addmm(x[2], A, B, beta=be, alpha=al)      # one library GEMM with the bias folded in
+                else:
+                    y = al * (A @ B)
+                    if len(x) > 2 and x[2] is not None:
+                        y = y + be * x[2]
             elif op == "MatMul":
                 y = x[0] @ x[1]
             elif op in ("Add", "Sub", "Mul", "Div"):

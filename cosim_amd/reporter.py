@@ -24,18 +24,26 @@ class FleetReporter:
                       [f"tracking_err_{i}" for i in range(min(cd, 3))])
         self.acc = MetricsAccumulator(self.names, device=env.device)
         self.trace = []
+        self._row = None
+        self._fast = hasattr(env, "info_buf") and hasattr(env, "user_command")   # BatchedEnv: the info dict is views of these
         self.steps = 0
         self.episodes_ended = 0
 
     def write_info(self, info: dict):
         t = self.env.torch
-        cols = [info["action_diff_RMSE"], info["lin_vel_x"], info["lin_vel_y"], info["ang_vel_yaw"]]
-        cols += [info["torque"][:, i].abs() for i in range(self.env.action_dim)]
-        # command tracking (reporter.py:506-508): applied command 0,1 vs base linear velocity, 2 vs yaw rate
-        meas = [info["lin_vel_x"], info["lin_vel_y"], info["ang_vel_yaw"]]
-        for i in range(min(self.env.command_dim, 3)):
-            cols.append((info[f"user_command_{i}"] - meas[i]).abs())
-        self.acc.update(t.stack([c.to(t.float32) for c in cols], dim=1))
+        nu, cd = self.env.action_dim, min(self.env.command_dim, 3)
+        # one row per env: [action_diff_RMSE, lin_vel_x, lin_vel_y, ang_vel_yaw, |torque|..., |command - measured|...]
+        # (command tracking as in reporter.py:506-508: applied command 0, 1 vs base linear velocity, 2 vs yaw rate)
+        if self._row is None:
+            self._row = t.empty((self.env.num_envs, len(self.names)), dtype=t.float32, device=self.env.device)
+        base = t.cat([info["action_diff_RMSE"][:, None], info["lin_vel_x"][:, None], info["lin_vel_y"][:, None], info["ang_vel_yaw"][:, None]], dim=1) \
+            if not self._fast else self.env.info_buf[:, :4]
+        self._row[:, :4] = base
+        t.abs(info["torque"], out=self._row[:, 4:4 + nu])
+        if cd:
+            cmd = t.stack([info[f"user_command_{i}"] for i in range(cd)], dim=1) if not self._fast else self.env.user_command[:, :cd]
+            t.abs(cmd - self._row[:, 1:1 + cd], out=self._row[:, 4 + nu:4 + nu + cd])
+        self.acc.update(self._row)
         self.steps += 1
         if self.trace_env is not None:
             i = self.trace_env
