@@ -1382,6 +1382,9 @@ static void fwd_acceleration(oracle_data* d) {
   chol_solve(d->L, nv, d->qacc_smooth);
 }
 
+long g_warm_total = 0, g_warm_smooth = 0; /* diagnostics: how often qacc_smooth beats the warm start */
+int g_warm_always = 0;                    /* diagnostics: 1 = always start from qacc_warmstart (what the HIP engine does) */
+void oracle_warm_stats(long* out2, int always) { out2[0] = g_warm_total; out2[1] = g_warm_smooth; g_warm_always = always; }
 static void fwd_constraint(oracle_data* d) { /* mj_fwdConstraint incl. warmstart selection */
   const cosim_model_t* m = &d->m;
   int nv = m->nv;
@@ -1406,7 +1409,9 @@ static void fwd_constraint(oracle_data* d) { /* mj_fwdConstraint incl. warmstart
     jar[i] = s;
   }
   double cost_smooth = constraint_update(d, jar, force, state);
-  memcpy(d->qacc, cost_warm > cost_smooth ? d->qacc_smooth : d->qacc_warmstart, nv * sizeof(double));
+  g_warm_total++;
+  if (cost_warm > cost_smooth) g_warm_smooth++;
+  memcpy(d->qacc, (cost_warm > cost_smooth && !g_warm_always) ? d->qacc_smooth : d->qacc_warmstart, nv * sizeof(double));
   solve_newton(d);
 }
 
