@@ -1118,11 +1118,13 @@ __global__ __launch_bounds__(64, (RPL == 1 && EPW == 1) ? 4 : 2) void env_kernel
 
       // per-lane row state: row (ln + LW rr), rr < RPL
       int rtype[RPL], rdof[RPL];
-      float rsign[RPL], rfloss[RPL], rD[RPL], rR[RPL], raref[RPL], rpos_dbg = 0.f;
+      // rlo < x < rhi: the row's quadratic zone in x = J a - aref (equality: all x; frictionloss: |x| < R f; limit / contact:
+      // x < 0); outside it the cost is linear with slope -+rfloss (0 for limit / contact) and offset rh0 = -R f^2 / 2
+      float rsign[RPL], rfloss[RPL], rD[RPL], rlo[RPL], rhi[RPL], rh0[RPL], raref[RPL], rpos_dbg = 0.f;
 #pragma unroll
       for (int rr = 0; rr < RPL; rr++) {
         const int row = ln + LW * rr;
-        rtype[rr] = RT_NONE; rdof[rr] = 0; rsign[rr] = 1.f; rfloss[rr] = 0.f; rD[rr] = 0.f; rR[rr] = 1.f; raref[rr] = 0.f;
+        rtype[rr] = RT_NONE; rdof[rr] = 0; rsign[rr] = 1.f; rfloss[rr] = 0.f; rD[rr] = 0.f; rlo[rr] = -3.0e38f; rhi[rr] = 3.0e38f; rh0[rr] = 0.f; raref[rr] = 0.f;
         float rpos = 0.f, rmargin = 0.f, rdiagA = 0.f, rmu = 0.f;
         float rsolref[2] = {0.02f, 1.f}, rsolimp[5] = {0.9f, 0.95f, 0.001f, 0.5f, 2.f};
         if (row < ngen) {
@@ -1195,7 +1197,7 @@ __global__ __launch_bounds__(64, (RPL == 1 && EPW == 1) ? 4 : 2) void env_kernel
             rdiagA = S.p_dinvw[rdof[rr]];
             for (int k = 0; k < 2; k++) rsolref[k] = D.d_solref[k];
             for (int k = 0; k < 5; k++) rsolimp[k] = D.d_solimp[k];
-            if (!(rfloss[rr] > 0.f)) rtype[rr] = RT_NONE;
+            if (!(rfloss[rr] > 0.f)) { rtype[rr] = RT_NONE; rfloss[rr] = 0.f; }
           } else {
             rtype[rr] = RT_LIMIT;
             const int li = row - ngen - nf;
@@ -1221,9 +1223,11 @@ __global__ __launch_bounds__(64, (RPL == 1 && EPW == 1) ? 4 : 2) void env_kernel
             B = 2.f / fmaxf(MINVAL, dmax * tc);
           } else { K = -rsolref[0] / fmaxf(MINVAL, dmax * dmax); B = -rsolref[1] / fmaxf(MINVAL, dmax); }
           if (rtype[rr] == RT_FRIC) K = 0.f;
-          rR[rr] = fmaxf(MINVAL, (1.f - imp) * rdiagA / imp);
-          if (rtype[rr] == RT_CONTACT) { float mu = rmu * rsqrtf(fmaxf(MINVAL, dm.impratio)); rR[rr] = 2.f * mu * mu * rR[rr]; }
-          rD[rr] = 1.f / rR[rr];
+          float rR = fmaxf(MINVAL, (1.f - imp) * rdiagA / imp);
+          if (rtype[rr] == RT_CONTACT) { float mu = rmu * rsqrtf(fmaxf(MINVAL, dm.impratio)); rR = 2.f * mu * mu * rR; }
+          rD[rr] = 1.f / rR;
+          if (rtype[rr] == RT_FRIC) { const float Rf = rR * rfloss[rr]; rlo[rr] = -Rf; rhi[rr] = Rf; rh0[rr] = -0.5f * Rf * rfloss[rr]; }
+          else if (rtype[rr] != RT_EQ) rhi[rr] = 0.f;   // limit, contact: quadratic for x < 0, zero beyond
           float vel;
           if (rtype[rr] == RT_EQ || rtype[rr] == RT_CONTACT) {
             vel = 0.f;
@@ -1278,17 +1282,13 @@ __global__ __launch_bounds__(64, (RPL == 1 && EPW == 1) ? 4 : 2) void env_kernel
         if (ln < NV) { S.dofD[ln] = 0.f; S.qcon[ln] = 0.f; }
 #pragma unroll
         for (int rr = 0; rr < RPL; rr++) {
+          // branch-free over the row kinds (lanes of one wave hold different kinds): rows of kind NONE carry D = 0, f = 0
           const float x = Jaref[rr];
-          float f = 0.f, c = 0.f, dact = 0.f;
-          if (rtype[rr] == RT_EQ) { f = -rD[rr] * x; c = 0.5f * rD[rr] * x * x; dact = rD[rr]; }
-          else if (rtype[rr] == RT_FRIC) {
-            float Rf = rR[rr] * rfloss[rr];
-            if (x <= -Rf) { f = rfloss[rr]; c = -0.5f * Rf * rfloss[rr] - rfloss[rr] * x; }
-            else if (x >= Rf) { f = -rfloss[rr]; c = -0.5f * Rf * rfloss[rr] + rfloss[rr] * x; }
-            else { f = -rD[rr] * x; c = 0.5f * rD[rr] * x * x; dact = rD[rr]; }
-          } else if (rtype[rr] == RT_LIMIT || rtype[rr] == RT_CONTACT) {
-            if (x < 0.f) { f = -rD[rr] * x; c = 0.5f * rD[rr] * x * x; dact = rD[rr]; }
-          }
+          const bool inq = x > rlo[rr] && x < rhi[rr];
+          const float sf = x <= rlo[rr] ? rfloss[rr] : -rfloss[rr];          // force on the linear branches (0 for limit / contact)
+          const float f = inq ? -rD[rr] * x : sf;
+          const float c = inq ? 0.5f * rD[rr] * x * x : rh0[rr] - sf * x;
+          const float dact = inq ? rD[rr] : 0.f;
           dact_cur[rr] = dact;
           csum += c;
           S.w.r.rowf[ln + LW * rr] = f;
@@ -1441,15 +1441,11 @@ __global__ __launch_bounds__(64, (RPL == 1 && EPW == 1) ? 4 : 2) void env_kernel
 #pragma unroll
           for (int rr = 0; rr < RPL; rr++) {
             const float x = Jaref[rr] + alpha * Jv[rr];
-            if (rtype[rr] == RT_EQ) { c0 += q0[rr]; c1 += q1[rr]; c2 += q2[rr]; }
-            else if (rtype[rr] == RT_FRIC) {
-              float Rf = rR[rr] * rfloss[rr];
-              if (x > -Rf && x < Rf) { c0 += q0[rr]; c1 += q1[rr]; c2 += q2[rr]; }
-              else if (x <= -Rf) { c0 += rfloss[rr] * (-0.5f * Rf - Jaref[rr]); c1 += -rfloss[rr] * Jv[rr]; }
-              else { c0 += rfloss[rr] * (-0.5f * Rf + Jaref[rr]); c1 += rfloss[rr] * Jv[rr]; }
-            } else if (rtype[rr] == RT_LIMIT || rtype[rr] == RT_CONTACT) {
-              if (x < 0.f) { c0 += q0[rr]; c1 += q1[rr]; c2 += q2[rr]; }
-            }
+            const bool inq = x > rlo[rr] && x < rhi[rr];
+            const float sf = x <= rlo[rr] ? rfloss[rr] : -rfloss[rr];
+            c0 += inq ? q0[rr] : rh0[rr] - sf * Jaref[rr];
+            c1 += inq ? q1[rr] : -sf * Jv[rr];
+            c2 += inq ? q2[rr] : 0.f;
           }
           float C0 = grp_sum<LW>(c0) + gauss, C1 = grp_sum<LW>(c1) + qG1, C2 = grp_sum<LW>(c2) + qG2;
           Pnt p;
