@@ -1131,12 +1131,15 @@ __global__ __launch_bounds__(64, (RPL == 1 && EPW == 1) ? 4 : 2) void env_kernel
           float* Jr = S.J[row];
 #pragma unroll
           for (int d = 0; d < NV; d++) Jr[d] = 0.f;
+          // equality and contact rows share one Jacobian loop: J = +jac(chain A, point A) - jac(chain B, point B) along `dir`
+          float dir[3], offA[3], offB[3];
+          unsigned maskA, maskB;
           if (row < ne) {
             rtype[rr] = RT_EQ;
             const int e = row / 3, comp = row - 3 * e;
             const LaneRec& E = dm.rec[e];
             const int b1 = E.e_body1, b2 = E.e_body2;
-            float dir[3] = {comp == 0 ? 1.f : 0.f, comp == 1 ? 1.f : 0.f, comp == 2 ? 1.f : 0.f};
+            dir[0] = comp == 0 ? 1.f : 0.f; dir[1] = comp == 1 ? 1.f : 0.f; dir[2] = comp == 2 ? 1.f : 0.f;
             float p1[3], p2[3], v[3], q1[4] = {S.xquat[b1][0], S.xquat[b1][1], S.xquat[b1][2], S.xquat[b1][3]},
                                       q2[4] = {S.xquat[b2][0], S.xquat[b2][1], S.xquat[b2][2], S.xquat[b2][3]};
             qrot(v, q1, E.e_anchor1);
@@ -1144,19 +1147,8 @@ __global__ __launch_bounds__(64, (RPL == 1 && EPW == 1) ? 4 : 2) void env_kernel
             qrot(v, q2, E.e_anchor2);
             for (int k = 0; k < 3; k++) p2[k] = S.xpos[b2][k] + v[k];
             rpos = p1[comp] - p2[comp];
-            float off[3], od[3];
-            for (int k = 0; k < 3; k++) off[k] = p1[k] - com[k];
-            cross(od, off, dir);
-            for (unsigned mk = dm.rec[b1].b_dofmask; mk; mk &= mk - 1) {
-              const int j = __builtin_ctz(mk);
-              Jr[j] += dir[0] * S.cdof[j][3] + dir[1] * S.cdof[j][4] + dir[2] * S.cdof[j][5] + od[0] * S.cdof[j][0] + od[1] * S.cdof[j][1] + od[2] * S.cdof[j][2];
-            }
-            for (int k = 0; k < 3; k++) off[k] = p2[k] - com[k];
-            cross(od, off, dir);
-            for (unsigned mk = dm.rec[b2].b_dofmask; mk; mk &= mk - 1) {
-              const int j = __builtin_ctz(mk);
-              Jr[j] -= dir[0] * S.cdof[j][3] + dir[1] * S.cdof[j][4] + dir[2] * S.cdof[j][5] + od[0] * S.cdof[j][0] + od[1] * S.cdof[j][1] + od[2] * S.cdof[j][2];
-            }
+            for (int k = 0; k < 3; k++) { offA[k] = p1[k] - com[k]; offB[k] = p2[k] - com[k]; }
+            maskA = dm.rec[b1].b_dofmask; maskB = dm.rec[b2].b_dofmask;
             rdiagA = S.p_binvw[b1] + S.p_binvw[b2];
             for (int k = 0; k < 2; k++) rsolref[k] = E.e_solref[k];
             for (int k = 0; k < 5; k++) rsolimp[k] = E.e_solimp[k];
@@ -1171,22 +1163,30 @@ __global__ __launch_bounds__(64, (RPL == 1 && EPW == 1) ? 4 : 2) void env_kernel
             make_frame(nrm, t1, t2);
             const float* tk = (edge >> 1) ? t2 : t1;
             const float sg = (edge & 1) ? -mu : mu;
-            float dir[3] = {nrm[0] + sg * tk[0], nrm[1] + sg * tk[1], nrm[2] + sg * tk[2]};
-            float off[3] = {S.cpos[c][0] - com[0], S.cpos[c][1] - com[1], S.cpos[c][2] - com[2]}, od[3];
-            cross(od, off, dir);
-            // mj_jacDifPair: jac(body2) - jac(body1); dofs common to both chains cancel
+            for (int k = 0; k < 3; k++) { dir[k] = nrm[k] + sg * tk[k]; offA[k] = S.cpos[c][k] - com[k]; offB[k] = offA[k]; }
+            // mj_jacDifPair: jac(body2) - jac(body1) at one point; dofs common to both chains cancel
             const unsigned m2 = dm.rec[b].b_dofmask, m1 = (SC && g1 >= 0) ? dm.rec[b1].b_dofmask : 0u;
-            for (unsigned mk = m2 ^ m1; mk; mk &= mk - 1) {
-              const int j = __builtin_ctz(mk);
-              const float jv = dir[0] * S.cdof[j][3] + dir[1] * S.cdof[j][4] + dir[2] * S.cdof[j][5] + od[0] * S.cdof[j][0] + od[1] * S.cdof[j][1] + od[2] * S.cdof[j][2];
-              Jr[j] = ((m2 >> j) & 1u) ? jv : -jv;
-            }
+            maskA = m2 & ~m1; maskB = m1 & ~m2;
             rpos = S.cdist[c];
             rmargin = G.g_incmargin;
             rmu = mu;
             rdiagA = (S.p_binvw[b] + ((SC && g1 >= 0) ? S.p_binvw[b1] : 0.f)) * (1.f + mu * mu);
             for (int k = 0; k < 2; k++) rsolref[k] = G.g_solref[k];
             for (int k = 0; k < 5; k++) rsolimp[k] = G.g_solimp[k];
+          }
+          {
+            float odA[3], odB[3];
+            cross(odA, offA, dir);
+            cross(odB, offB, dir);
+            for (unsigned mk = maskA | maskB; mk; mk &= mk - 1) {
+              const int j = __builtin_ctz(mk);
+              const float lin = dir[0] * S.cdof[j][3] + dir[1] * S.cdof[j][4] + dir[2] * S.cdof[j][5];
+              const float a0 = S.cdof[j][0], a1 = S.cdof[j][1], a2 = S.cdof[j][2];
+              float v = 0.f;
+              if ((maskA >> j) & 1u) v += lin + odA[0] * a0 + odA[1] * a1 + odA[2] * a2;
+              if ((maskB >> j) & 1u) v -= lin + odB[0] * a0 + odB[1] * a1 + odB[2] * a2;
+              Jr[j] = v;
+            }
           }
         } else if (row < nefc) {
           if (row < ngen + nf) {

@@ -68,7 +68,7 @@ class Runner:
         env = self.env
         state, _ = env.reset()
         steps = 0
-        done_all = False
+        done_all, done_seen = False, None
         while not done_all and not self._stop and (max_steps is None or steps < max_steps):
             env.receive_user_command(self.user_command)            # tester.py:68
             action = self.policy.get_action(state)                 # :70
@@ -81,7 +81,10 @@ class Runner:
                 on_step(steps, state, terminated, truncated, info)
             steps += 1
             if not env.auto_reset:
-                done_all = bool((terminated | truncated).all().item())
+                # every env has ended an episode at least once (they need not end in the same step: a non-finite state
+                # restarts one env early)
+                done_seen = (terminated | truncated) if done_seen is None else (done_seen | terminated | truncated)
+                done_all = bool(done_seen.all().item())
         return steps
 
     def test_graphed(self, max_steps: int, warmup: int = 3) -> int:
