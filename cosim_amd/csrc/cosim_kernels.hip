@@ -666,12 +666,19 @@ __global__ __launch_bounds__(64, (RPL == 1 && EPW == 1) ? 4 : 2) void env_kernel
 
       STAMP(2);   // comPos + cdof
       // =========================================================== mj_crb: composite inertia of the dof's body, M row + column
+      // the whole tree's composite inertia (what the free joint's six dofs need) is a sum over all body lanes: ten group
+      // reductions instead of a 13-body loop that every lane of the wave would have to sit through
+      const unsigned allbodies = ((nbody >= 32 ? 0u : (1u << nbody)) - 1u) & ~1u;
+      float crb_all[10];
+#pragma unroll
+      for (int k = 0; k < 10; k++) crb_all[k] = grp_sum<LW>((ln > 0 && ln < nbody) ? cinert[k] : 0.f);
       if (ln < NV) {
         const LaneRec& R = dm.rec[ln];
         float crb[10];
+        const unsigned sub = dm.rec[R.d_body].b_subtree;
 #pragma unroll
-        for (int k = 0; k < 10; k++) crb[k] = 0.f;
-        for (unsigned mk = dm.rec[R.d_body].b_subtree; mk; mk &= mk - 1) {
+        for (int k = 0; k < 10; k++) crb[k] = sub == allbodies ? crb_all[k] : 0.f;
+        for (unsigned mk = sub == allbodies ? 0u : sub; mk; mk &= mk - 1) {
           const int c = __builtin_ctz(mk);
 #pragma unroll
           for (int k = 0; k < 10; k++) crb[k] += S.w.cin[c][k];
@@ -723,6 +730,7 @@ __global__ __launch_bounds__(64, (RPL == 1 && EPW == 1) ? 4 : 2) void env_kernel
         for (int q = 0; q < 6; q++) S.u.v.cdd[ln][q] = cdd[q];
       }
       WSYNC();
+      float cfb_l[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // this body's inertial + Coriolis wrench (lane = body)
       if (ln > 0 && ln < nbody) {
         const LaneRec& R = dm.rec[ln];
         float cvel_b[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -745,13 +753,19 @@ __global__ __launch_bounds__(64, (RPL == 1 && EPW == 1) ? 4 : 2) void env_kernel
           t3[3] = c[0]; t3[4] = c[1]; t3[5] = c[2];
         }
 #pragma unroll
-        for (int q = 0; q < 6; q++) S.u.v.cfb[ln][q] = t1[q] + t3[q];
+        for (int q = 0; q < 6; q++) { cfb_l[q] = t1[q] + t3[q]; S.u.v.cfb[ln][q] = cfb_l[q]; }
       }
       WSYNC();
+      float cfb_all[6];   // the whole tree's wrench, for the free joint's dofs: group reductions instead of a 13-body loop
+#pragma unroll
+      for (int q = 0; q < 6; q++) cfb_all[q] = grp_sum<LW>(cfb_l[q]);
       if (ln < NV) {
         const LaneRec& R = dm.rec[ln];
-        float f[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        for (unsigned mk = dm.rec[R.d_body].b_subtree; mk; mk &= mk - 1) {
+        const unsigned sub = dm.rec[R.d_body].b_subtree;
+        float f[6];
+#pragma unroll
+        for (int q = 0; q < 6; q++) f[q] = sub == allbodies ? cfb_all[q] : 0.f;
+        for (unsigned mk = sub == allbodies ? 0u : sub; mk; mk &= mk - 1) {
           const int c = __builtin_ctz(mk);
 #pragma unroll
           for (int q = 0; q < 6; q++) f[q] += S.u.v.cfb[c][q];
