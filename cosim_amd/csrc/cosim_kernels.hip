@@ -963,25 +963,34 @@ __global__ __launch_bounds__(64, (RPL == 1 && EPW == 1) ? 4 : 2) void env_kernel
           int bi = (best == bmin) ? besti : 0x7fffffff;  // lowest vertex index among ties, like a sequential scan
 #pragma unroll
           for (int o = LW / 2; o > 0; o >>= 1) bi = min(bi, __shfl_xor(bi, o, 64));
+          // candidates of mjc_PlaneConvex: the support vertex (candidate 0), then its hull neighbours in list order; the
+          // first four within the margin become contacts.  One lane per candidate: one round of dependent loads, not a
+          // serial walk that the whole wave would wait on.
+          const int lo = A.hull_adr[adr + bi], nnb = A.hull_adr[adr + bi + 1] - lo;
           int added = 0;
-          for (int pass = 0; pass < 2; pass++) {
-            const int lo = pass ? A.hull_adr[adr + bi] : 0, hi = pass ? A.hull_adr[adr + bi + 1] : 1;
-            for (int e = lo; e < hi && added < 4; e++) {
-              const int i = pass ? A.hull_nbr[e] : bi;
+          for (int c0 = 0; c0 < nnb + 1 && added < 4; c0 += LW) {
+            const int cand = c0 + ln;
+            bool okc = false;
+            float dist = 0.f, cpw[3] = {0.f, 0.f, 0.f};
+            if (cand < nnb + 1) {
+              const int i = cand == 0 ? bi : A.hull_nbr[lo + cand - 1];
               const float* v = A.hull_vert + 3 * (adr + i);
-              const float dist = offn + lnv[0] * v[0] + lnv[1] * v[1] + lnv[2] * v[2];
-              if (dist > gmargin) continue;
+              dist = offn + lnv[0] * v[0] + lnv[1] * v[1] + lnv[2] * v[2];
+              okc = !(dist > gmargin);
               const float w[3] = {m[0] * v[0] + m[1] * v[1] + m[2] * v[2], m[3] * v[0] + m[4] * v[1] + m[5] * v[2], m[6] * v[0] + m[7] * v[1] + m[8] * v[2]};
-              const float cpw[3] = {gxp[0] + w[0] - n[0] * dist * 0.5f, gxp[1] + w[1] - n[1] * dist * 0.5f, gxp[2] + w[2] - n[2] * dist * 0.5f};
-              added++;
-              if (ncon < MC && ln == 0) {
-                S.cdist[ncon] = dist;
-                S.cgeom[ncon] = g;
-                for (int k = 0; k < 3; k++) { S.cpos[ncon][k] = cpw[k]; if (NRM) S.cnrm[NRM ? ncon : 0][k] = n[k]; }
-              }
-              ncon++;
+              for (int k = 0; k < 3; k++) cpw[k] = gxp[k] + w[k] - n[k] * dist * 0.5f;
             }
+            const unsigned long long km = grp_ballot<LW>(okc, hb);
+            const int rank = added + __popcll(km & lanemask_lt(ln));
+            if (okc && rank < 4 && ncon + rank < MC) {
+              const int slot = ncon + rank;
+              S.cdist[slot] = dist;
+              S.cgeom[slot] = g;
+              for (int k = 0; k < 3; k++) { S.cpos[slot][k] = cpw[k]; if (NRM) S.cnrm[NRM ? slot : 0][k] = n[k]; }
+            }
+            added += __popcll(km);
           }
+          ncon += min(added, 4);
         }
       }
 
