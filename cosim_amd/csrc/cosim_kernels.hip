@@ -78,13 +78,13 @@ __device__ __forceinline__ float row_sum(float v) {
   v += dpp<0x140>(v);
   return v;
 }
+// rows 1 and 3 += lane 15 of the row before (row_bcast15, row mask 0xA); rows 2 and 3 += lane 31 (row_bcast31, row mask 0xC):
+// lane 63 then holds the wave total -- two DPP adds and one readlane instead of four readlanes and three adds
 __device__ __forceinline__ float wave_sum(float v) {
   v = row_sum(v);
-  float s = rl(v, 0);
-  s += rl(v, 16);
-  s += rl(v, 32);
-  s += rl(v, 48);
-  return s;
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x142, 0xA, 0xF, false));
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x143, 0xC, 0xF, false));
+  return rl(v, 63);
 }
 __device__ __forceinline__ float wave_min(float v) {
   v = fminf(v, dpp<0xB1>(v));
