@@ -1632,6 +1632,7 @@ __global__ __launch_bounds__(64, (RPL == 1 && EPW == 1) ? 4 : 2) void env_kernel
         const float rhs = ln < NV ? qsm_l + S.qcon[ln] : 0.f;
         const float qa = chol_solve_lds<NV, L::LD, LW>(S.u.H, dinv, rhs, ln, hb);
         WSYNC();
+        if (PROF) { __builtin_amdgcn_s_waitcnt(0); unsigned long long t_ = __builtin_amdgcn_s_memtime(); pacc[15] += t_ - pt0; }   // implicit solve done (advance follows)
         if (A.mode != MODE_DEBUG) {
           if (ln < NV) S.qvel[ln] = qv + h * qa;
           WSYNC();

@@ -23,8 +23,8 @@ for t in range(300, 300 + K):
 acc /= K
 names = ["prologue", "kinematics", "comPos+cdof", "crb (M)", "comVel+rne+sensors", "collision", "constraint rows", "Newton total",
          "implicitfast+advance", "obs+info epilogue", "  Newton: Hessian (MFMA)", "  Newton: Cholesky+park", "  Newton: tri. solves",
-         "  Newton: line search", "  Newton: move+constraint update", ""]
+         "  Newton: line search", "  Newton: move+constraint update", "  implicitfast: factor + solve (rest = advance)"]
 tot = acc[:10].sum()
 print(f"mean wave lifetime {tot:.0f} cycles per control step (4 substeps), diagnostic build, {N} envs resident")
-for i in list(range(10)) + [10, 11, 12, 13, 14]:
+for i in list(range(10)) + [10, 11, 12, 13, 14, 15]:
     print(f"  {names[i]:34s} {acc[i]:10.0f} cycles  {100*acc[i]/tot:5.1f} %")
