@@ -244,24 +244,28 @@ __device__ __forceinline__ void chol_lower(float (&a)[NV], float& dinv, int lane
     for (int k = j + 1; k < NV; k++) a[k] -= a[j] * grp_bcast<LW>(a[j], k, hb);  // lane k's a[j] = L[k][j]
   }
 }
-// solve (L L^T) x = b with L stored row-major in LDS (Lm[i][k], k <= i valid); lane i holds b_i and returns x_i.
-// Forward substitution reads row i, backward substitution reads column i (consecutive lanes -> consecutive banks).
+// solve (L L^T) x = b.  L = D L1 with D = diag(L) and L1 unit lower triangular; the LDS matrix holds the strictly lower part
+// of L1 (row i scaled by 1 / L[i][i], zeros on and above the diagonal -- see chol_park), so
+//   L y = b    <=>  L1 y = D^-1 b         and        L^T x = y   <=>  L1^T (D x) = y,
+// and a substitution stage is one broadcast, one LDS read and one FMA with no lane masking (the zeros do it).
+// Lane i holds b_i and returns x_i; forward reads row i, backward reads column i (consecutive lanes -> consecutive banks).
 template <int NV, int LD, int LW>
 __device__ __forceinline__ float chol_solve_lds(const float (*Lm)[LD], float dinv, float b, int lane, int hb) {
   const int li = lane < NV ? lane : 0;
+  b *= dinv;
 #pragma unroll
-  for (int j = 0; j < NV; j++) {
-    const float yj = grp_bcast<LW>(b, j, hb) * grp_bcast<LW>(dinv, j, hb);
-    const float upd = b - Lm[li][j] * yj;
-    b = (lane == j) ? yj : ((lane > j) ? upd : b);
-  }
+  for (int j = 0; j < NV - 1; j++) b -= Lm[li][j] * grp_bcast<LW>(b, j, hb);
 #pragma unroll
-  for (int j = NV - 1; j >= 0; j--) {
-    const float xj = grp_bcast<LW>(b, j, hb) * grp_bcast<LW>(dinv, j, hb);
-    const float upd = b - Lm[j][li] * xj;
-    b = (lane == j) ? xj : ((lane < j) ? upd : b);
+  for (int j = NV - 1; j > 0; j--) b -= Lm[j][li] * grp_bcast<LW>(b, j, hb);
+  return b * dinv;
+}
+// row `lane` of the factor into LDS in the form chol_solve_lds reads
+template <int NV, int LD>
+__device__ __forceinline__ void chol_park(float (*Lm)[LD], const float (&a)[NV], float dinv, int lane) {
+  if (lane < NV) {
+#pragma unroll
+    for (int k = 0; k < NV; k++) Lm[lane][k] = k < lane ? a[k] * dinv : 0.f;
   }
-  return b;
 }
 
 
@@ -1413,10 +1417,7 @@ __global__ __launch_bounds__(64, (RPL == 1 && EPW == 1) ? 4 : 2) void env_kernel
           }
           chol_lower<NV, LW>(a_row, dinv, ln, hb);
           WSYNC();
-          if (ln < NV) {
-#pragma unroll
-            for (int k = 0; k < NV; k++) S.u.H[ln][k] = a_row[k];
-          }
+          chol_park<NV, L::LD>(S.u.H, a_row, dinv, ln);
           WSYNC();
         }
         if (PROF) { __builtin_amdgcn_s_waitcnt(0); unsigned long long t_ = __builtin_amdgcn_s_memtime(); pacc[11] += t_ - q0_; q0_ = t_; }   // Cholesky + park
@@ -1624,10 +1625,7 @@ __global__ __launch_bounds__(64, (RPL == 1 && EPW == 1) ? 4 : 2) void env_kernel
         }
         chol_lower<NV, LW>(a_row, dinv, ln, hb);
         WSYNC();
-        if (ln < NV) {
-#pragma unroll
-          for (int k = 0; k < NV; k++) S.u.H[ln][k] = a_row[k];
-        }
+        chol_park<NV, L::LD>(S.u.H, a_row, dinv, ln);
         WSYNC();
         const float rhs = ln < NV ? qsm_l + S.qcon[ln] : 0.f;
         const float qa = chol_solve_lds<NV, L::LD, LW>(S.u.H, dinv, rhs, ln, hb);
