@@ -540,6 +540,13 @@ __global__ __launch_bounds__(64, (RPL == 1 && EPW == 1) ? 4 : 2) void env_kernel
         const LaneRec& R = dm.rec[ln];
         const int b_level = ln < nbody ? R.b_level : -1;
         const int maxdepth = dm.maxdepth;
+        // the joint's own rotation depends on this body's qpos only: one sincos per body ahead of the sweep, not one per level
+        float ql[4] = {1.f, 0.f, 0.f, 0.f};
+        if (b_level > 0 && R.b_jtype == CS_JNT_HINGE) {
+          float sn, cs;
+          sincosf(0.5f * (S.qpos[R.b_qadr] - R.j_q0), &sn, &cs);
+          ql[0] = cs; ql[1] = R.j_axis[0] * sn; ql[2] = R.j_axis[1] * sn; ql[3] = R.j_axis[2] * sn;
+        }
         for (int lev = 1; lev <= maxdepth; lev++) {
           if (b_level == lev) {
             const int b = ln, jt = R.b_jtype;
@@ -563,10 +570,6 @@ __global__ __launch_bounds__(64, (RPL == 1 && EPW == 1) ? 4 : 2) void env_kernel
                 qrot(v, xq, R.j_pos);
                 for (int k = 0; k < 3; k++) anc[k] = xp[k] + v[k];
                 qrot(ax, xq, R.j_axis);
-                float ang = S.qpos[R.b_qadr] - R.j_q0;
-                float sn, cs;
-                sincosf(0.5f * ang, &sn, &cs);
-                float ql[4] = {cs, R.j_axis[0] * sn, R.j_axis[1] * sn, R.j_axis[2] * sn};
                 qmul(xq, xq, ql);
                 qrot(v, xq, R.j_pos);
                 for (int k = 0; k < 3; k++) xp[k] = anc[k] - v[k];
