@@ -1413,10 +1413,13 @@ __global__ __launch_bounds__(64, (RPL == 1 && EPW == 1) ? 4 : 2) void env_kernel
           if (PROF) { __builtin_amdgcn_s_waitcnt(0); unsigned long long t_ = __builtin_amdgcn_s_memtime(); pacc[10] += t_ - q0_; q0_ = t_; }   // Hessian build
           float a_row[NV];
           {
+            // unit rows (frictionloss, limits) only touch the diagonal: added in LDS (one dynamic access) so that the row
+            // comes out as plain reads; lanes past NV factor a copy of row 0, which nobody reads
+            if (ln < NV) S.u.H[ln][ln] += S.dofD[ln];
+            WSYNC();
             const float* Hr = S.u.H[ln < NV ? ln : 0];
-            const float dd = ln < NV ? S.dofD[ln] : 0.f;  // unit rows (frictionloss, limits) only touch the diagonal
 #pragma unroll
-            for (int k = 0; k < NV; k++) a_row[k] = (ln < NV ? Hr[k] : 0.f) + ((ln == k) ? dd : 0.f);
+            for (int k = 0; k < NV; k++) a_row[k] = Hr[k];
           }
           chol_lower<NV, LW>(a_row, dinv, ln, hb);
           WSYNC();
@@ -1621,10 +1624,12 @@ __global__ __launch_bounds__(64, (RPL == 1 && EPW == 1) ? 4 : 2) void env_kernel
       {
         float a_row[NV];
         {
+          // M + h diag(damping): the diagonal term goes into LDS (M is rebuilt next substep), the row is plain reads
+          if (ln < NV) S.M[ln][ln] += h * dm.rec[ln].d_damping;
+          WSYNC();
           const float* Mr = S.M[ln < NV ? ln : 0];
-          const float hd = ln < NV ? h * dm.rec[ln].d_damping : 0.f;
 #pragma unroll
-          for (int k = 0; k < NV; k++) a_row[k] = (ln < NV ? Mr[k] : 0.f) + ((ln == k) ? hd : 0.f);
+          for (int k = 0; k < NV; k++) a_row[k] = Mr[k];
         }
         chol_lower<NV, LW>(a_row, dinv, ln, hb);
         WSYNC();
