@@ -1465,7 +1465,7 @@ __global__ __launch_bounds__(64, (RPL == 1 && EPW == 1) ? 4 : 2) void env_kernel
         if (!(snorm >= 1e-20f)) return false;
         const float qG1 = grp_sum<LW>(sr_l * (Ma - qsm_l)), qG2 = grp_sum<LW>(0.5f * sr_l * Mv);
         const float gtol = A.tol32 * dm.ls_tolerance * snorm / scale;
-        struct Pnt { float alpha, cost, d0, d1; };
+        struct Pnt { float alpha, cost, d0, d1, step; };   // step = -d0 / d1 (Newton step of the 1-D search; v_rcp_f32: 1 ulp is ample)
         auto eval = [&](float alpha) -> Pnt {
           float c0 = 0.f, c1 = 0.f, c2 = 0.f;
 #pragma unroll
@@ -1484,6 +1484,7 @@ __global__ __launch_bounds__(64, (RPL == 1 && EPW == 1) ? 4 : 2) void env_kernel
           p.d0 = 2.f * alpha * C2 + C1;
           p.d1 = 2.f * C2;
           if (!(p.d1 > 0.f)) p.d1 = 1e-15f;
+          p.step = -p.d0 * __builtin_amdgcn_rcpf(p.d1);
           return p;
         };
         float alpha = 0.f;
@@ -1498,8 +1499,9 @@ __global__ __launch_bounds__(64, (RPL == 1 && EPW == 1) ? 4 : 2) void env_kernel
             const float gs = grp_sum<LW>(grad_l * sr_l);
             p0.alpha = 0.f; p0.cost = cost; p0.d0 = gs; p0.d1 = -gs;
             if (!(p0.d1 > 0.f)) p0.d1 = 1e-15f;
+            p0.step = -p0.d0 * __builtin_amdgcn_rcpf(p0.d1);
           }
-          Pnt p1 = eval(p0.alpha - p0.d0 / p0.d1); lsit++;
+          Pnt p1 = eval(p0.alpha + p0.step); lsit++;
           if (p0.cost < p1.cost) p1 = p0;
           bool done = false;
           if (fabsf(p1.d0) < gtol) { alpha = p1.alpha; done = true; }
@@ -1510,7 +1512,7 @@ __global__ __launch_bounds__(64, (RPL == 1 && EPW == 1) ? 4 : 2) void env_kernel
 #pragma nounroll
             while (p1.d0 * dir <= -gtol && lsit < maxls) {
               p2 = p1; p2update = true;
-              p1 = eval(p1.alpha - p1.d0 / p1.d1); lsit++;
+              p1 = eval(p1.alpha + p1.step); lsit++;
               if (fabsf(p1.d0) < gtol) { alpha = p1.alpha; done = true; break; }
             }
             if (!done) {
@@ -1518,7 +1520,7 @@ __global__ __launch_bounds__(64, (RPL == 1 && EPW == 1) ? 4 : 2) void env_kernel
             }
             if (!done) {
               Pnt p2next = p1;
-              Pnt p1next = eval(p1.alpha - p1.d0 / p1.d1); lsit++;
+              Pnt p1next = eval(p1.alpha + p1.step); lsit++;
 #pragma nounroll
               while (lsit < maxls) {
                 Pnt pmid = eval(0.5f * (p1.alpha + p2.alpha)); lsit++;
@@ -1537,9 +1539,9 @@ __global__ __launch_bounds__(64, (RPL == 1 && EPW == 1) ? 4 : 2) void env_kernel
   if (P.d0 < 0.f && C.d0 < 0.f && P.d0 < C.d0) { P = C; FLAG = 1; }                                    \
   else if (P.d0 > 0.f && C.d0 > 0.f && P.d0 > C.d0) { P = C; FLAG = 2; }
                 BRACKET_UPDATE(p1, c0_, b1) BRACKET_UPDATE(p1, c1_, b1) BRACKET_UPDATE(p1, c2_, b1)
-                if (b1) { p1next = eval(p1.alpha - p1.d0 / p1.d1); lsit++; }
+                if (b1) { p1next = eval(p1.alpha + p1.step); lsit++; }
                 BRACKET_UPDATE(p2, c0_, b2) BRACKET_UPDATE(p2, c1_, b2) BRACKET_UPDATE(p2, c2_, b2)
-                if (b2) { p2next = eval(p2.alpha - p2.d0 / p2.d1); lsit++; }
+                if (b2) { p2next = eval(p2.alpha + p2.step); lsit++; }
 #undef BRACKET_UPDATE
                 if (!b1 && !b2) { alpha = pmid.alpha; done = true; break; }
               }
