@@ -30,7 +30,7 @@ struct LaneRec {
   unsigned b_dofmask;  // bit d: dof d is on the chain from the root to this body
   float b_pos[3], b_quat[4], b_ipos[3], b_iquat[4], b_inertia[3], j_pos[3], j_axis[3], j_q0;
   int j_limited;
-  float j_range[2], j_margin, j_solref[2], j_solimp[5];
+  float j_range[2], j_margin, j_solref[2] /* all *_solref: (K, B) of mj_makeImpedance, filled by the host */, j_solimp[5];
   // ---- dof (index = dof id)
   int d_body, d_parent, d_frclimited, d_act, d_fric /* i-th dof that carries a frictionloss row */;
   unsigned d_ancmask;  // ancestors of this dof incl. itself
@@ -57,6 +57,7 @@ struct DevModel {
   int ground_type, hfield_nrow, hfield_ncol, nhullvert;
   int imu_body, term_mode, nterm_body, ntri;
   int nobs_pos, nobs_vel, ninfo_state, init_noise_nq;
+  int any_jpos;            // some hinge joint has an anchor away from its body's origin (none of the cosim robots does)
   unsigned imu_dofmask;
   unsigned term_bodymask;  // bodies whose cfrc_ext ends the episode (term_mode 1)
   float timestep, tolerance, ls_tolerance, impratio;

@@ -101,6 +101,8 @@ static int build_dev_model(cosim_engine* e) {
   if (m.neq > MAXEQ) return fail(COSIM_EINVAL, "too many equalities");
   if (m.ngeom > 24 || m.nu > m.nv - 6 || m.nq != m.nv + 1) return fail(COSIM_EINVAL, "model exceeds the per-env LDS tables (geoms <= 24, nu <= nv - 6, one free joint)");
   int maxdepth = 0;
+  for (int j = 0; j < m.njnt; j++)
+    if (m.jnt_type[j] == CS_JNT_HINGE && (m.jnt_pos[j][0] != 0.0 || m.jnt_pos[j][1] != 0.0 || m.jnt_pos[j][2] != 0.0)) d.any_jpos = 1;
   // dof ancestor masks
   unsigned anc[MAXD];
   for (int i = 0; i < m.nv; i++) anc[i] = (1u << i) | (m.dof_parentid[i] >= 0 ? anc[m.dof_parentid[i]] : 0u);
@@ -185,6 +187,24 @@ static int build_dev_model(cosim_engine* e) {
     for (int k = 0; k < 3; k++) { r.e_anchor1[k] = (float)m.eq_anchor1[q][k]; r.e_anchor2[k] = (float)m.eq_anchor2[q][k]; }
     for (int k = 0; k < 2; k++) r.e_solref[k] = (float)m.eq_solref[q][k];
     for (int k = 0; k < 5; k++) r.e_solimp[k] = (float)m.eq_solimp[q][k];
+  }
+  // solref -> (K, B) of mj_makeImpedance once on the host (they depend on solref, solimp[1] and the timestep only): the
+  // *_solref slots of the device records carry K and B from here on
+  {
+    auto kb = [&](float* solref, const float* solimp) {
+      const double dmax = fmin(0.9999, fmax(0.0001, (double)solimp[1]));
+      double K, B;
+      if (solref[0] > 0.f) {
+        const double tc = fmax((double)solref[0], 2.0 * m.timestep), dr = solref[1];   // refsafe
+        K = 1.0 / fmax(1e-15, dmax * dmax * tc * tc * dr * dr);
+        B = 2.0 / fmax(1e-15, dmax * tc);
+      } else { K = -(double)solref[0] / fmax(1e-15, dmax * dmax); B = -(double)solref[1] / fmax(1e-15, dmax); }
+      solref[0] = (float)K; solref[1] = (float)B;
+    };
+    for (int b = 0; b < m.nbody; b++) if (m.body_jntnum[b] == 1) kb(d.rec[b].j_solref, d.rec[b].j_solimp);
+    for (int i = 0; i < m.nv; i++) kb(d.rec[i].d_solref, d.rec[i].d_solimp);
+    for (int g = 0; g < m.ngeom; g++) kb(d.rec[g].g_solref, d.rec[g].g_solimp);
+    for (int q = 0; q < m.neq; q++) kb(d.rec[q].e_solref, d.rec[q].e_solimp);
   }
   for (int u = 0; u < m.nu; u++) {
     LaneRec& r = d.rec[u];

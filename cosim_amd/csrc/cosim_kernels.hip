@@ -567,12 +567,17 @@ __global__ __launch_bounds__(64, (RPL == 1 && EPW == 1 && !HF) ? 4 : 2) void env
               for (int k = 0; k < 3; k++) xp[k] = S.xpos[p][k] + v[k];
               qmul(xq, pq, R.b_quat);
               if (jt == CS_JNT_HINGE) {
-                qrot(v, xq, R.j_pos);
-                for (int k = 0; k < 3; k++) anc[k] = xp[k] + v[k];
                 qrot(ax, xq, R.j_axis);
-                qmul(xq, xq, ql);
-                qrot(v, xq, R.j_pos);
-                for (int k = 0; k < 3; k++) xp[k] = anc[k] - v[k];
+                if (dm.any_jpos) {   // anchor away from the body origin: the origin swings around it
+                  qrot(v, xq, R.j_pos);
+                  for (int k = 0; k < 3; k++) anc[k] = xp[k] + v[k];
+                  qmul(xq, xq, ql);
+                  qrot(v, xq, R.j_pos);
+                  for (int k = 0; k < 3; k++) xp[k] = anc[k] - v[k];
+                } else {
+                  for (int k = 0; k < 3; k++) anc[k] = xp[k];
+                  qmul(xq, xq, ql);
+                }
               }
               qnorm(xq);
             }
@@ -1156,7 +1161,7 @@ __global__ __launch_bounds__(64, (RPL == 1 && EPW == 1 && !HF) ? 4 : 2) void env
         const int row = ln + LW * rr;
         rtype[rr] = RT_NONE; rdof[rr] = 0; rsign[rr] = 1.f; rfloss[rr] = 0.f; rD[rr] = 0.f; rlo[rr] = -3.0e38f; rhi[rr] = 3.0e38f; rh0[rr] = 0.f; raref[rr] = 0.f;
         float rpos = 0.f, rmargin = 0.f, rdiagA = 0.f, rmu = 0.f;
-        float rsolref[2] = {0.02f, 1.f}, rsolimp[5] = {0.9f, 0.95f, 0.001f, 0.5f, 2.f};
+        float rsolref[2] = {0.f, 0.f} /* (K, B) */, rsolimp[5] = {0.9f, 0.95f, 0.001f, 0.5f, 2.f};
         if (row < ngen) {
           float* Jr = S.J[row];
 #pragma unroll
@@ -1245,13 +1250,7 @@ __global__ __launch_bounds__(64, (RPL == 1 && EPW == 1 && !HF) ? 4 : 2) void env
         // KBIP, R, D, aref
         if (rtype[rr] != RT_NONE) {
           float imp = impedance(rsolimp, rpos, rmargin);
-          float dmax = fminf(MAXIMP, fmaxf(MINIMP, rsolimp[1]));
-          float K, B;
-          if (rsolref[0] > 0.f) {
-            float tc = fmaxf(rsolref[0], 2.f * h), dr = rsolref[1];
-            K = 1.f / fmaxf(MINVAL, dmax * dmax * tc * tc * dr * dr);
-            B = 2.f / fmaxf(MINVAL, dmax * tc);
-          } else { K = -rsolref[0] / fmaxf(MINVAL, dmax * dmax); B = -rsolref[1] / fmaxf(MINVAL, dmax); }
+          float K = rsolref[0], B = rsolref[1];   // stiffness and damping of the reference acceleration, precomputed on the host
           if (rtype[rr] == RT_FRIC) K = 0.f;
           float rR = fmaxf(MINVAL, (1.f - imp) * rdiagA / imp);
           if (rtype[rr] == RT_CONTACT) { float mu = rmu * rsqrtf(fmaxf(MINVAL, dm.impratio)); rR = 2.f * mu * mu * rR; }
@@ -1371,11 +1370,11 @@ __global__ __launch_bounds__(64, (RPL == 1 && EPW == 1 && !HF) ? 4 : 2) void env
               const int row = (v & 3) + 8 * (v >> 2) + 4 * half;
               acc[v] = (row < NV && col < NV) ? S.M[row < NV ? row : 0][col < NV ? col : 0] : 0.f;
             }
+            const int colc = col < NV ? col : 0;   // lanes past NV feed tile rows / columns that are never stored
             for (int r0 = 0; r0 < ngen; r0 += 2) {
               const int r = r0 + half;
-              const bool ok = r < ngen && col < NV;
-              const float jv = ok ? S.J[ok ? r : 0][ok ? col : 0] : 0.f;
-              const float dv = ok ? S.w.r.rowD[ok ? r : 0] : 0.f;
+              const float jv = r < ngen ? S.J[r < ngen ? r : 0][colc] : 0.f;
+              const float dv = S.w.r.rowD[r < ngen ? r : 0];
               acc = __builtin_amdgcn_mfma_f32_32x32x2f32(jv * dv, jv, acc, 0, 0, 0);
             }
 #pragma unroll
