@@ -1236,6 +1236,8 @@ static int update_bracket(primal_ctx* c, primal_pnt* p, const primal_pnt cand[3]
   return flag;
 }
 
+long g_ls_stat[6] = {0, 0, 0, 0, 0, 0}; /* diagnostics: searches, done after p1, one-sided Newton evals, bracket entries, bracket evals, total evals */
+void oracle_ls_stats(long* out6) { for (int i = 0; i < 6; i++) out6[i] = g_ls_stat[i]; }
 static double primal_search(primal_ctx* c) { /* PrimalSearch: exact line search on the piecewise-quadratic cost */
   oracle_data* d = c->d;
   const cosim_model_t* m = &d->m;
@@ -1266,10 +1268,11 @@ static double primal_search(primal_ctx* c) { /* PrimalSearch: exact line search 
     c->quad[i][2] = 0.5 * D * c->Jv[i] * c->Jv[i];
   }
   primal_pnt p0, p1, p2, pmid, p1next, p2next;
+  g_ls_stat[0]++;
   p0.alpha = 0; primal_eval(c, &p0);
   p1.alpha = p0.alpha - p0.deriv[0] / p0.deriv[1]; primal_eval(c, &p1);
   if (p0.cost < p1.cost) p1 = p0;
-  if (fabs(p1.deriv[0]) < gtol) return p1.alpha;
+  if (fabs(p1.deriv[0]) < gtol) { g_ls_stat[1]++; return p1.alpha; }
   int dir = p1.deriv[0] < 0 ? 1 : -1;
   int p2update = 0;
   p2 = p1;
@@ -1277,14 +1280,18 @@ static double primal_search(primal_ctx* c) { /* PrimalSearch: exact line search 
     p2 = p1; p2update = 1;
     p1.alpha -= p1.deriv[0] / p1.deriv[1];
     primal_eval(c, &p1);
+    g_ls_stat[2]++;
     if (fabs(p1.deriv[0]) < gtol) return p1.alpha;
   }
   if (c->lsiter >= maxiter) return p1.alpha;
   if (!p2update) return p1.alpha;
   p2next = p1;
+  g_ls_stat[3]++;
+  { int before = c->lsiter; (void)before; }
   p1next.alpha = p1.alpha - p1.deriv[0] / p1.deriv[1]; primal_eval(c, &p1next);
   while (c->lsiter < maxiter) {
     pmid.alpha = 0.5 * (p1.alpha + p2.alpha); primal_eval(c, &pmid);
+    g_ls_stat[4]++;
     primal_pnt cand[3] = {p1next, p2next, pmid};
     int best = -1;
     double bestcost = 0;
