@@ -1160,7 +1160,7 @@ __global__ __launch_bounds__(64, (RPL == 1 && EPW == 1 && !HF) ? 4 : 2) void env
       for (int rr = 0; rr < RPL; rr++) {
         const int row = ln + LW * rr;
         rtype[rr] = RT_NONE; rdof[rr] = 0; rsign[rr] = 1.f; rfloss[rr] = 0.f; rD[rr] = 0.f; rlo[rr] = -3.0e38f; rhi[rr] = 3.0e38f; rh0[rr] = 0.f; raref[rr] = 0.f;
-        float rpos = 0.f, rmargin = 0.f, rdiagA = 0.f, rmu = 0.f;
+        float rpos = 0.f, rmargin = 0.f, rdiagA = 0.f, rmu = 0.f, rvel = 0.f;
         float rsolref[2] = {0.f, 0.f} /* (K, B) */, rsolimp[5] = {0.9f, 0.95f, 0.001f, 0.5f, 2.f};
         if (row < ngen) {
           float* Jr = S.J[row];
@@ -1221,6 +1221,7 @@ __global__ __launch_bounds__(64, (RPL == 1 && EPW == 1 && !HF) ? 4 : 2) void env
               if ((maskA >> j) & 1u) v += lin + odA[0] * a0 + odA[1] * a1 + odA[2] * a2;
               if ((maskB >> j) & 1u) v -= lin + odB[0] * a0 + odB[1] * a1 + odB[2] * a2;
               Jr[j] = v;
+              rvel += v * S.qvel[j];   // J qvel over the dofs the row touches
             }
           }
         } else if (row < nefc) {
@@ -1257,13 +1258,7 @@ __global__ __launch_bounds__(64, (RPL == 1 && EPW == 1 && !HF) ? 4 : 2) void env
           rD[rr] = 1.f / rR;
           if (rtype[rr] == RT_FRIC) { const float Rf = rR * rfloss[rr]; rlo[rr] = -Rf; rhi[rr] = Rf; rh0[rr] = -0.5f * Rf * rfloss[rr]; }
           else if (rtype[rr] != RT_EQ) rhi[rr] = 0.f;   // limit, contact: quadratic for x < 0, zero beyond
-          float vel;
-          if (rtype[rr] == RT_EQ || rtype[rr] == RT_CONTACT) {
-            vel = 0.f;
-            const float* Jr = S.J[row];
-#pragma unroll
-            for (int d = 0; d < NV; d++) vel += Jr[d] * S.qvel[d];
-          } else vel = rsign[rr] * S.qvel[rdof[rr]];
+          const float vel = (rtype[rr] == RT_EQ || rtype[rr] == RT_CONTACT) ? rvel : rsign[rr] * S.qvel[rdof[rr]];
           raref[rr] = -B * vel - K * imp * (rpos - rmargin);
         }
         if (rr == 0) rpos_dbg = rpos;
