@@ -174,3 +174,42 @@ def test_height_map_on_flat_terrain_is_refused():
         make_obs_config(cfg, obs_to_dim("w4_p_v2", cfg), 50.0, True)
     ok = make_config("w4_p_v2", terrain="rocky_easy", height_map=True)
     make_obs_config(ok, obs_to_dim("w4_p_v2", ok), 50.0, True)
+
+
+def test_one_env_info_stream_is_accepted_by_the_reference_reporter(tmp_path):
+    """SURVEY §8b 'info contract (Reporter drop-in)' / §8f N2: the single-env dicts that Runner / FleetReporter cut out of the
+    batched info are fed to the reference's own core/reporter.py (importable here: matplotlib only), which must build its PDF.
+    Skipped where the reference tree is not mounted (the GPU box)."""
+    ref = "/root/reference/core/reporter.py"
+    if not os.path.exists(ref):
+        pytest.skip("reference tree not mounted")
+    import importlib.util
+    import torch
+    from cosim_amd.runner import Runner
+    spec = importlib.util.spec_from_file_location("ref_reporter", ref)
+    mod = importlib.util.module_from_spec(spec)
+    try:
+        spec.loader.exec_module(mod)
+    except ImportError as e:
+        pytest.skip(f"reference reporter not importable here: {e}")
+
+    class FakeEnv:                       # the attributes Runner reads; info tensors shaped like BatchedEnv._info's
+        num_envs, command_dim, auto_reset = 8, 4, False
+    N, nu = 8, 4
+    run = Runner.__new__(Runner)
+    run.env = FakeEnv()
+    cfg = make_config("flamingo_light_v1")
+    rep = mod.Reporter(str(tmp_path / "report.pdf"), cfg)
+    g = torch.Generator().manual_seed(0)
+    for t in range(60):
+        buf = torch.randn((N, 4 + 3 * nu), generator=g)
+        info = {"dt": 0.02, "action": torch.randn((N, nu), generator=g), "action_diff_RMSE": buf[:, 0], "lin_vel_x": buf[:, 1],
+                "lin_vel_y": buf[:, 2], "ang_vel_yaw": buf[:, 3], "torque": buf[:, 4:4 + nu], "set_points": buf[:, 4 + nu:4 + 2 * nu],
+                "state": buf[:, 4 + 2 * nu:]}
+        for i in range(4):
+            info[f"user_command_{i}"] = torch.full((N,), 0.1 * i)
+        one = run._one_env_info(info, 3)
+        assert isinstance(one["lin_vel_x"], float) and one["torque"].shape == (nu,) and one["dt"] == 0.02
+        rep.write_info(one)
+    rep.generate_report()
+    assert os.path.getsize(tmp_path / "report.pdf") > 10000
