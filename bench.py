@@ -97,15 +97,29 @@ def cpu_baseline(sample_envs=16, sample_steps=12000):
     with ThreadPoolExecutor(nthr) as ex:
         done = sum(ex.map(worker, range(nthr)))
     t_mt = time.perf_counter() - t0
+    ref_leg = None
     try:
-        import mujoco  # noqa: F401
-        ref = "mujoco importable on this host: tools/crosscheck_mujoco.py compares and times it (not run by bench.py)"
-    except Exception:
-        ref = "reference MuJoCo CPU path unavailable on this host"
+        import mujoco  # the reference's own engine, if this host happens to have it (nothing is installed for it)
+        sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+        from tools.crosscheck_mujoco import build_xml
+        mj_model = mujoco.MjModel.from_xml_string(build_xml(cfg))
+        mj_data = mujoco.MjData(mj_model)
+        mj_data.qpos[:] = q0
+        mujoco.mj_forward(mj_model, mj_data)
+        n_ref, t0 = 0, time.perf_counter()
+        while time.perf_counter() - t0 < 5.0:                      # zero torque, frame_skip substeps per control step
+            mujoco.mj_step(mj_model, mj_data, nstep=int(cm.blob.frame_skip))
+            n_ref += 1
+        ref_leg = {"value": n_ref / (time.perf_counter() - t0), "unit": "env-steps/s", "cores": 1, "kind": "reference",
+                   "sample": f"mujoco {mujoco.__version__} mj_step x {int(cm.blob.frame_skip)} on the same MJCF (hull vertices inline), 1 env, zero torque, 5 s"}
+        ref = "reference MuJoCo timed beside it (cpu_baseline.reference)"
+    except Exception as e:  # noqa: BLE001
+        ref = f"reference MuJoCo CPU path unavailable on this host ({type(e).__name__})"
     return {"value": n_steps / t_total, "unit": "env-steps/s", "cores": 1, "kind": "port",
             "sample": f"{sample_envs} envs x {sample_steps} control steps of {ROBOT} flat, sinusoid actions, fp64 oracle, "
                       f"1 thread of {os.cpu_count()} host cores ({t_total:.1f} s); {ref}",
-            "threads": {"value": done / t_mt, "cores": nthr, "sample": f"{nthr} threads x 1 env x {mt_steps} control steps ({t_mt:.1f} s)"}}
+            "threads": {"value": done / t_mt, "cores": nthr, "sample": f"{nthr} threads x 1 env x {mt_steps} control steps ({t_mt:.1f} s)"},
+            **({"reference": ref_leg} if ref_leg else {})}
 
 
 def pmc_traffic(workload):
