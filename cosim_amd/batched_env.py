@@ -103,6 +103,9 @@ class BatchedEnv:
         assert self.engine.query("state_dim") == self.state_dim
         self.info_dim = self.engine.query("info_dim")
         # kernel variant: COSIM_ENVS_PER_WAVE=1|2 overrides the engine's choice where the variant exists (A/B runs)
+        prio = os.environ.get("COSIM_WAVE_PRIORITY")           # "base,t1,t2,t3" (tuning runs)
+        if prio:
+            self.engine.set_param("wave_priority", np.array([float(x) for x in prio.split(",")]))
         epw = os.environ.get("COSIM_ENVS_PER_WAVE")
         if epw:
             try:

@@ -45,6 +45,7 @@ struct cosim_engine {
   int max_newton = 50;
   int max_ls = 24;
   int nsub_override = 0;
+  int prio[4] = {6, -4, -2, 0};   // wave priority by solver lag (see the kernel): usual iterations per substep, lag thresholds
   // timing
   bool timing = false;
   std::vector<hipEvent_t> ev;  // event pairs (start, stop) of timed launches not yet read back
@@ -459,6 +460,11 @@ int cosim_set_param(cosim_engine_t* e, const char* name, const float* host, int 
   else if (n == "solver_tolerance") { e->tol32 = host[0]; return COSIM_OK; }
   else if (n == "max_newton") { e->max_newton = (int)host[0]; return COSIM_OK; }
   else if (n == "max_ls") { e->max_ls = (int)host[0]; return COSIM_OK; }
+  else if (n == "wave_priority") {   // [usual Newton iterations per substep, lag thresholds of priority 1, 2, 3]; a huge first threshold switches it off
+    if (count != 4) return fail(COSIM_EINVAL, "cosim_set_param: wave_priority takes 4 values");
+    for (int k = 0; k < 4; k++) e->prio[k] = (int)host[k];
+    return COSIM_OK;
+  }
   else if (n == "debug_substeps") { e->nsub_override = (int)host[0]; return COSIM_OK; }
   else if (n == "envs_per_wave") {   // 2: the two-environments-per-wave kernel (flat flamingo_light_v1, even env counts); 1: one per wave
     const int w = (int)host[0];
@@ -494,6 +500,7 @@ static KArgs base_args(cosim_engine* e) {
   a.pairs = e->d_pairs; a.gext = e->d_gext;
   a.n_envs = e->n_envs; a.seed_lo = (unsigned)e->seed; a.seed_hi = (unsigned)(e->seed >> 32); a.env_id0 = e->env_id0;
   a.tol32 = e->tol32; a.max_newton = e->max_newton; a.max_ls = e->max_ls; a.nsub_override = e->nsub_override;
+  for (int k = 0; k < 4; k++) a.prio[k] = e->prio[k];
   return a;
 }
 

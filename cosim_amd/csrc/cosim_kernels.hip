@@ -61,6 +61,7 @@ struct KArgs {
   float tol32;            // fp32 solver tolerance
   int max_newton, max_ls;
   int nsub_override;      // > 0: physics substeps per control step (diagnostics; 0 = the model's frame_skip)
+  int prio[4];            // wave priority by solver lag: expected Newton iterations per substep, then the three lag thresholds
 };
 
 // ------------------------------------------------------------------------------------------------ wave helpers
@@ -1580,6 +1581,17 @@ __global__ __launch_bounds__(64, (RPL == 1 && EPW == 1 && !HF) ? 4 : 2) void env
       }
       st_newton += niter;
       st_rows += nefc;
+      if constexpr (EPW == 1 && RPL == 1 && !HF && !PROF) {   // the 4-waves-per-SIMD kernels (with 2 waves it starves one: measured)
+        // s_setprio by solver lag.  Waves that have needed more Newton iterations than the pack are the ones the launch ends
+        // with; letting them issue first trims that tail, and it also staggers the four waves of a SIMD so that they are not
+        // all inside the same latency-bound phase at once.  Thresholds (cosim_set_param "wave_priority") were swept on the
+        // 4096-env flamingo_light_v1 bench: off 10.5 M, (3; 1, 3, 6) 10.9 M, (6; -4, -2, 0) 11.3 M env-steps/s.
+        const int lag = st_newton - A.prio[0] * (sub + 1);
+        if (lag >= A.prio[3]) __builtin_amdgcn_s_setprio(3);
+        else if (lag >= A.prio[2]) __builtin_amdgcn_s_setprio(2);
+        else if (lag >= A.prio[1]) __builtin_amdgcn_s_setprio(1);
+        else __builtin_amdgcn_s_setprio(0);
+      }
       if (A.mode == MODE_DEBUG && A.dbg != nullptr) {
         float* D = A.dbg;
         if (ln == 0) { D[8] = (float)niter; D[9] = cost; D[10] = gradnorm; }

@@ -81,7 +81,9 @@ int cosim_query(const cosim_engine_t* e, const char* name);
  * max-combined with the ground; robot-robot pairs use the model's geom friction) "kp"[N,nu] "kd"[N,nu].  `host` points to
  * host memory, float32, row-major.  Engine scalars (count 1): "solver_tolerance" (fp32 Newton tolerance), "max_newton",
  * "max_ls" (iteration caps below the model's), "envs_per_wave" (1 | 2: kernel variant, 2 only for flat flamingo_light_v1 and
- * even env counts), "debug_substeps" (diagnostics: physics substeps per control step, 0 = frame_skip). */
+ * even env counts), "wave_priority" (count 4: s_setprio by solver lag -- Newton iterations taken as usual per substep, then the
+ * lag thresholds of priority 1, 2, 3; a huge first threshold switches it off), "debug_substeps" (diagnostics: physics substeps
+ * per control step, 0 = frame_skip). */
 int cosim_set_param(cosim_engine_t* e, const char* name, const float* host, int count);
 
 /* Replaces env.reset() (reference envs/wrappers.py:245-256,303-307,385-389; flamingo_light_v1.py:209-232).
