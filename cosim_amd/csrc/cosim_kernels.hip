@@ -1568,6 +1568,22 @@ __global__ __launch_bounds__(64, (RPL == 1 && EPW == 1 && !HF) ? 4 : 2) void env
         const float improvement = scale * (oldcost - cost);
         return !(improvement < A.tol32);
       };
+      // s_setprio by solver lag, refreshed after every Newton iteration (4-waves-per-SIMD kernels; with 2 waves it starves
+      // one: measured).  Waves that have needed more iterations than the pack are the ones the launch ends with: letting them
+      // issue first trims that tail, and it staggers the four waves of a SIMD so that they are not all inside the same
+      // latency-bound phase at once.  lag = iterations so far - usual count + the wave's slot number on its SIMD
+      // (HW_REG_HW_ID.WAVE_ID & 3, a tie-break).  Thresholds (cosim_set_param "wave_priority") swept on the 4096-env
+      // flamingo_light_v1 bench: off 10.5 M, (3; 1, 3, 6) 10.9 M, (6; -4, -2, 0) 11.3 M, + tie-break 11.5 M, + per-iteration
+      // refresh 11.7 M env-steps/s.
+      auto wave_priority = [&](int iters_so_far) {
+        if constexpr (EPW == 1 && RPL == 1 && !HF && !PROF) {
+          const int lag = iters_so_far - A.prio[0] * (sub + 1) + (int)(__builtin_amdgcn_s_getreg(4 | (0 << 6) | (3 << 11)) & 3u);
+          if (lag >= A.prio[3]) __builtin_amdgcn_s_setprio(3);
+          else if (lag >= A.prio[2]) __builtin_amdgcn_s_setprio(2);
+          else if (lag >= A.prio[1]) __builtin_amdgcn_s_setprio(1);
+          else __builtin_amdgcn_s_setprio(0);
+        }
+      };
       // Environments of one wave iterate together: `act` marks the ones still running, the wave leaves when none is.
       bool act = true;
 #pragma nounroll
@@ -1578,21 +1594,10 @@ __global__ __launch_bounds__(64, (RPL == 1 && EPW == 1 && !HF) ? 4 : 2) void env
         if constexpr (EPW == 1) act = any;   // one environment: wave-uniform, keeps the body a scalar branch
         update_search(act);
         if (act) act = newton_iterate();
+        wave_priority(st_newton + niter);
       }
       st_newton += niter;
       st_rows += nefc;
-      if constexpr (EPW == 1 && RPL == 1 && !HF && !PROF) {   // the 4-waves-per-SIMD kernels (with 2 waves it starves one: measured)
-        // s_setprio by solver lag.  Waves that have needed more Newton iterations than the pack are the ones the launch ends
-        // with; letting them issue first trims that tail, and it also staggers the four waves of a SIMD so that they are not
-        // all inside the same latency-bound phase at once.  Thresholds (cosim_set_param "wave_priority") were swept on the
-        // 4096-env flamingo_light_v1 bench: off 10.5 M, (3; 1, 3, 6) 10.9 M, (6; -4, -2, 0) 11.3 M env-steps/s.
-        // (+ the wave's slot number on its SIMD, HW_REG_HW_ID.WAVE_ID & 3: breaks ties between equally advanced waves, +1.6 %)
-        const int lag = st_newton - A.prio[0] * (sub + 1) + (int)(__builtin_amdgcn_s_getreg(4 | (0 << 6) | (3 << 11)) & 3u);
-        if (lag >= A.prio[3]) __builtin_amdgcn_s_setprio(3);
-        else if (lag >= A.prio[2]) __builtin_amdgcn_s_setprio(2);
-        else if (lag >= A.prio[1]) __builtin_amdgcn_s_setprio(1);
-        else __builtin_amdgcn_s_setprio(0);
-      }
       if (A.mode == MODE_DEBUG && A.dbg != nullptr) {
         float* D = A.dbg;
         if (ln == 0) { D[8] = (float)niter; D[9] = cost; D[10] = gradnorm; }
