@@ -423,7 +423,7 @@ __device__ __forceinline__ float impedance(const float* solimp, float pos, float
 // HF: heightfield ground; SC: robot-robot (self) collision pairs; PROF: diagnostic build with s_memtime phase stamps;
 // EPW: environments per wave (1: lane l of 64 plays object l; 2: two groups of 32 lanes, RPL rows per lane of the group)
 template <int NV, int NB, int RPL, bool HF, int GTM, bool SC, bool PROF = false, int EPW = 1>
-__global__ __launch_bounds__(64, (RPL == 1 && EPW == 1 && !HF) ? 4 : 2) void env_kernel(KArgs A) {
+__global__ __launch_bounds__(64, (RPL == 1 && EPW == 1 && !HF) ? 4 : ((EPW == 1 && NV < 18) ? 3 : 2))   /* flamingo_p_v3: LDS allows 16 waves/CU, 3 per SIMD measured best */ void env_kernel(KArgs A) {
   static_assert(EPW == 1 || (EPW == 2 && !HF && !SC && NV <= 32 && NB <= 32), "two environments per wave: flat ground, no pairs");
   constexpr bool NRM = HF || SC;
   constexpr int LW = 64 / EPW;
