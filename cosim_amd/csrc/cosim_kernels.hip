@@ -423,7 +423,7 @@ __device__ __forceinline__ float impedance(const float* solimp, float pos, float
 // HF: heightfield ground; SC: robot-robot (self) collision pairs; PROF: diagnostic build with s_memtime phase stamps;
 // EPW: environments per wave (1: lane l of 64 plays object l; 2: two groups of 32 lanes, RPL rows per lane of the group)
 template <int NV, int NB, int RPL, bool HF, int GTM, bool SC, bool PROF = false, int EPW = 1>
-__global__ __launch_bounds__(64, (RPL == 1 && EPW == 1 && !HF) ? 4 : ((EPW == 1 && NV < 18) ? 3 : 2))   /* flamingo_p_v3: LDS allows 16 waves/CU, 3 per SIMD measured best */ void env_kernel(KArgs A) {
+__global__ __launch_bounds__(64, (RPL == 1 && EPW == 1 && !HF) ? 4 : ((EPW == 1 && NV < 18) ? 4 : 2))   /* flamingo_p_v3: LDS allows 16 waves/CU; 2 / 3 / 4 per SIMD measured 6.83 / 7.06 / 7.31 M env-steps/s */ void env_kernel(KArgs A) {
   static_assert(EPW == 1 || (EPW == 2 && !HF && !SC && NV <= 32 && NB <= 32), "two environments per wave: flat ground, no pairs");
   constexpr bool NRM = HF || SC;
   constexpr int LW = 64 / EPW;
@@ -1576,7 +1576,7 @@ __global__ __launch_bounds__(64, (RPL == 1 && EPW == 1 && !HF) ? 4 : ((EPW == 1 
       // flamingo_light_v1 bench: off 10.5 M, (3; 1, 3, 6) 10.9 M, (6; -4, -2, 0) 11.3 M, + tie-break 11.5 M, + per-iteration
       // refresh 11.7 M env-steps/s.
       auto wave_priority = [&](int iters_so_far) {
-        if constexpr (EPW == 1 && RPL == 1 && !HF && !PROF) {
+        if constexpr (EPW == 1 && ((RPL == 1 && !HF) || NV < 18) && !PROF) {
           const int lag = iters_so_far - A.prio[0] * (sub + 1) + (int)(__builtin_amdgcn_s_getreg(4 | (0 << 6) | (3 << 11)) & 3u);
           if (lag >= A.prio[3]) __builtin_amdgcn_s_setprio(3);
           else if (lag >= A.prio[2]) __builtin_amdgcn_s_setprio(2);
