@@ -10,6 +10,7 @@
 #include <vector>
 
 #include "cosim_kernels.hip"
+#include "cosim_mlp.hip"
 
 using namespace cosim;
 
@@ -322,6 +323,36 @@ static int upload_params(cosim_engine* e) {
 }
 
 extern "C" {
+
+// Fused actor MLP (cosim_mlp.hip): out = clip(act_L(... act_1(x W_1^T + b_1) ...)).  All pointers are device pointers; dims has
+// n_layers + 1 entries; act / act_alpha one entry per layer (0 none, 1 relu, 2 tanh, 3 elu, 4 sigmoid, 5 leaky relu).
+int cosim_mlp_forward(const float* x_dev, int n, int n_layers, const int* dims, const float* const* w_dev, const float* const* b_dev,
+                      const int* act, const float* act_alpha, float clip, float* out_dev, void* stream) {
+  if (!x_dev || !dims || !w_dev || !act || !out_dev || n <= 0) return fail(COSIM_EINVAL, "cosim_mlp_forward: bad argument");
+  if (n_layers < 1 || n_layers > MLP_MAXL) return fail(COSIM_EINVAL, "cosim_mlp_forward: 1..6 layers");
+  MlpArgs a;
+  memset(&a, 0, sizeof a);
+  int maxd = 0;
+  for (int l = 0; l <= n_layers; l++) {
+    if (dims[l] < 1 || dims[l] > MLP_MAXD) return fail(COSIM_EINVAL, "cosim_mlp_forward: layer width outside 1..512");
+    a.dims[l] = dims[l];
+    if (dims[l] > maxd) maxd = dims[l];
+  }
+  for (int l = 0; l < n_layers; l++) {
+    if (!w_dev[l]) return fail(COSIM_EINVAL, "cosim_mlp_forward: null weight");
+    a.w[l] = w_dev[l]; a.b[l] = b_dev ? b_dev[l] : nullptr; a.act[l] = act[l]; a.act_alpha[l] = act_alpha ? act_alpha[l] : 1.f;
+  }
+  a.x = x_dev; a.out = out_dev; a.nl = n_layers; a.n = n; a.clip = clip; a.ld = maxd | 1;
+  const size_t lds = (size_t)2 * 32 * a.ld * sizeof(float);
+  static size_t lds_allowed = 0;
+  if (lds > lds_allowed) {
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_forward_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    lds_allowed = lds;
+  }
+  hipLaunchKernelGGL(mlp_forward_kernel, dim3((n + 31) / 32), dim3(256), lds, (hipStream_t)stream, a);
+  HIP_TRY(hipGetLastError());
+  return COSIM_OK;
+}
 
 const char* cosim_last_error(void) { return g_err.c_str(); }
 int cosim_model_sizeof(void) { return (int)sizeof(cosim_model_t); }

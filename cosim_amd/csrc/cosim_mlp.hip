@@ -1,0 +1,103 @@
+// cosim_mlp.hip — fused forward pass of a small actor MLP on the matrix pipe.
+//
+// The reference evaluates its ONNX policy once per control step for one state (core/policy.py:11-21); for N environments
+// the same network is [N, in] -> hidden ... -> [N, action_dim].  Those layers are tiny (52 -> 256 -> 128 -> 4 for the
+// usual actor), so a chain of library GEMM + bias + activation launches is launch-bound: here one workgroup takes 32
+// environments through all layers, activations stay in LDS, weights stream from L2 and every product runs as
+// v_mfma_f32_32x32x2_f32 (exact fp32 FMA chains, like the CPU evaluation).
+//
+// Layout of one 32x32 output tile (lane l, register v): A[i = l & 31][k = l >> 5], B[k = l >> 5][j = l & 31];
+// C/D: col = l & 31, row = (v & 3) + 8 (v >> 2) + 4 (l >> 5)  (the layout the step kernel's Hessian build uses).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace cosim {
+
+constexpr int MLP_MAXL = 6;      // layers
+constexpr int MLP_MAXD = 512;    // widest layer: two ping-pong tiles of 32 x (width + 1) floats must fit the 160 KB LDS
+
+struct MlpArgs {
+  const float* x;      // [n, dims[0]]
+  float* out;          // [n, dims[nl]]
+  const float* w[MLP_MAXL];   // [dims[l+1], dims[l]] row-major (ONNX Gemm with transB = 1)
+  const float* b[MLP_MAXL];   // [dims[l+1]] or null
+  int dims[MLP_MAXL + 1];
+  int act[MLP_MAXL];   // 0 none, 1 relu, 2 tanh, 3 elu, 4 sigmoid, 5 leaky relu
+  float act_alpha[MLP_MAXL];
+  int nl, n, ld;       // ld: leading dimension of the LDS tiles (widest layer + 1: odd, conflict-free column reads)
+  float clip;          // > 0: clamp the output to [-clip, clip]
+};
+
+__device__ __forceinline__ float mlp_act(float x, int kind, float alpha) {
+  switch (kind) {
+    case 1: return fmaxf(x, 0.f);
+    case 2: return tanhf(x);
+    case 3: return x > 0.f ? x : alpha * (expf(x) - 1.f);
+    case 4: return 1.f / (1.f + expf(-x));
+    case 5: return x > 0.f ? x : alpha * x;
+    default: return x;
+  }
+}
+
+__global__ __launch_bounds__(256) void mlp_forward_kernel(MlpArgs A) {
+  typedef float f32x16 __attribute__((ext_vector_type(16)));
+  extern __shared__ float mlp_lds[];   // [2][32][ld]
+  const int ld = A.ld;
+  auto tile = [&](int which, int r, int c) -> float& { return mlp_lds[(which * 32 + r) * ld + c]; };
+  const int t = threadIdx.x, l = t & 63, wave = t >> 6;
+  const int n0 = blockIdx.x * 32;
+  // the input tile, coalesced
+  {
+    const int I = A.dims[0];
+    for (int e = t; e < 32 * I; e += 256) {
+      const int r = e / I, c = e - r * I;
+      tile(0, r, c) = (n0 + r < A.n) ? A.x[(size_t)(n0 + r) * I + c] : 0.f;
+    }
+  }
+  __syncthreads();
+  int cur = 0;
+  for (int L = 0; L < A.nl; L++) {
+    const int I = A.dims[L], O = A.dims[L + 1];
+    const float* W = A.w[L];
+    const float* Bv = A.b[L];
+    const bool last = L == A.nl - 1;
+    const int row_a = l & 31, kk = l >> 5;
+    for (int ti = wave; ti * 32 < O; ti += 4) {
+      const int o0 = ti * 32, col = o0 + (l & 31);
+      const float bias = (Bv != nullptr && col < O) ? Bv[col] : 0.f;
+      f32x16 acc;
+#pragma unroll
+      for (int v = 0; v < 16; v++) acc[v] = bias;
+      const float* wrow = W + (size_t)(col < O ? col : 0) * I;
+      if ((I & 3) == 0) {   // four weights of the lane's row per load: k0 + kk and k0 + 2 + kk feed two MFMA steps
+        for (int k0 = 0; k0 < I; k0 += 4) {
+          const float4 w4 = col < O ? *reinterpret_cast<const float4*>(wrow + k0) : make_float4(0.f, 0.f, 0.f, 0.f);
+          const float a0 = tile(cur, row_a, k0 + kk), a1 = tile(cur, row_a, k0 + 2 + kk);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, kk ? w4.y : w4.x, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, kk ? w4.w : w4.z, acc, 0, 0, 0);
+        }
+      } else {
+        for (int k0 = 0; k0 < I; k0 += 2) {
+          const int k = k0 + kk;
+          const float a = k < I ? tile(cur, row_a, k) : 0.f;
+          const float b = (k < I && col < O) ? wrow[k] : 0.f;
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+        }
+      }
+#pragma unroll
+      for (int v = 0; v < 16; v++) {
+        const int row = (v & 3) + 8 * (v >> 2) + 4 * (l >> 5);
+        float y = mlp_act(acc[v], A.act[L], A.act_alpha[L]);
+        if (last) {
+          if (A.clip > 0.f) y = fminf(A.clip, fmaxf(-A.clip, y));
+          if (col < O && n0 + row < A.n) A.out[(size_t)(n0 + row) * O + col] = y;
+        } else if (col < O)
+          tile(cur ^ 1, row, col) = y;
+      }
+    }
+    __syncthreads();
+    cur ^= 1;
+  }
+}
+
+}  // namespace cosim

@@ -258,22 +258,91 @@ class OnnxGraph:
 
 
 # ---------------------------------------------------------------------------------------------- the reference's classes, batched
-class MLPPolicy:
-    """``core/policy.py:5-21``: ``get_action(state[N, state_dim]) -> action[N, action_dim]`` in [-1, 1]."""
+_ACT = {"Relu": 1, "Tanh": 2, "Elu": 3, "Sigmoid": 4, "LeakyRelu": 5}
 
-    def __init__(self, policy_path: str, device=None):
+
+def _mlp_chain(model: dict):
+    """The graph as a plain actor MLP -- Gemm(transB=1, alpha=beta=1) [+ activation] ... -- or None if it is anything else."""
+    nodes, init = model["nodes"], model["init"]
+    if len(model["inputs"]) != 1 or len(model["outputs"]) != 1:
+        return None
+    layers, cur, i = [], model["inputs"][0], 0
+    while i < len(nodes):
+        n = nodes[i]
+        a = n["attrs"]
+        if n["op"] != "Gemm" or n["inputs"][0] != cur or a.get("transB", 0) != 1 or a.get("transA", 0) or \
+                a.get("alpha", 1.0) != 1.0 or a.get("beta", 1.0) != 1.0 or n["inputs"][1] not in init:
+            return None
+        w = init[n["inputs"][1]]
+        b = init.get(n["inputs"][2]) if len(n["inputs"]) > 2 and n["inputs"][2] else None
+        if w.ndim != 2 or w.dtype != np.float32 or (b is not None and (b.shape != (w.shape[0],) or b.dtype != np.float32)):
+            return None
+        cur, act, alpha = n["outputs"][0], 0, 1.0
+        i += 1
+        if i < len(nodes) and nodes[i]["op"] in _ACT and nodes[i]["inputs"] == [cur]:
+            act = _ACT[nodes[i]["op"]]
+            alpha = float(nodes[i]["attrs"].get("alpha", 1.0 if act == 3 else 0.01))
+            cur = nodes[i]["outputs"][0]
+            i += 1
+        layers.append((w, b, act, alpha))
+    if cur != model["outputs"][0] or not 1 <= len(layers) <= 6 or any(max(w.shape) > 512 for w, *_ in layers):
+        return None
+    return layers
+
+
+class MLPPolicy:
+    """``core/policy.py:5-21``: ``get_action(state[N, state_dim]) -> action[N, action_dim]`` in [-1, 1].
+
+    A graph that is a plain Gemm / activation chain runs as ONE launch of the engine's fused MFMA kernel
+    (``cosim_mlp_forward``, csrc/cosim_mlp.hip) when the policy lives on a GPU; anything else goes through the interpreter."""
+
+    def __init__(self, policy_path: str, device=None, fused: Optional[bool] = None):
+        import ctypes
         import torch
         self.torch = torch
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
-        self.graph = OnnxGraph(read_onnx(policy_path), self.device)
+        model = read_onnx(policy_path)
+        self.graph = OnnxGraph(model, self.device)
         self.input_name = self.graph.inputs[0]
+        chain = _mlp_chain(model) if (fused is not False and self.device.type == "cuda") else None
+        if fused and chain is None:
+            raise ValueError("fused=True needs a Gemm/activation chain on a GPU device")
+        self._fused = None
+        if chain is not None:
+            from .engine import load_library
+            L = load_library()
+            L.cosim_mlp_forward.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                            ctypes.c_void_p, ctypes.c_void_p, ctypes.c_float, ctypes.c_void_p, ctypes.c_void_p]
+            L.cosim_last_error.restype = ctypes.c_char_p
+            ws = [torch.as_tensor(np.ascontiguousarray(w), device=self.device) for w, *_ in chain]
+            bs = [None if b is None else torch.as_tensor(np.ascontiguousarray(b), device=self.device) for _, b, *_ in chain]
+            nl = len(chain)
+            self._fused = dict(
+                L=L, nl=nl, keep=(ws, bs),
+                dims=(ctypes.c_int * (nl + 1))(chain[0][0].shape[1], *[w.shape[0] for w, *_ in chain]),
+                w=(ctypes.c_void_p * nl)(*[w.data_ptr() for w in ws]),
+                b=(ctypes.c_void_p * nl)(*[None if b is None else b.data_ptr() for b in bs]),
+                act=(ctypes.c_int * nl)(*[a for *_, a, _ in chain]),
+                alpha=(ctypes.c_float * nl)(*[al for *_, al in chain]),
+                out_dim=chain[-1][0].shape[0], in_dim=chain[0][0].shape[1], out=None)
 
     def get_action(self, state):
         t = self.torch
         s = t.as_tensor(state, dtype=t.float32, device=self.device)
         single = s.dim() == 1
-        out = self.graph.run({self.input_name: s.unsqueeze(0) if single else s})[0]
-        out = out.clamp(-1.0, 1.0)
+        x = s.unsqueeze(0) if single else s
+        f = self._fused
+        if f is not None and x.shape[1] == f["in_dim"]:
+            x = x.contiguous()
+            if f["out"] is None or f["out"].shape[0] != x.shape[0]:
+                f["out"] = t.empty((x.shape[0], f["out_dim"]), dtype=t.float32, device=self.device)
+            rc = f["L"].cosim_mlp_forward(x.data_ptr(), x.shape[0], f["nl"], f["dims"], f["w"], f["b"], f["act"], f["alpha"], 1.0,
+                                          f["out"].data_ptr(), t.cuda.current_stream(self.device).cuda_stream)
+            if rc != 0:
+                raise RuntimeError(f["L"].cosim_last_error().decode())
+            out = f["out"]
+        else:
+            out = self.graph.run({self.input_name: x})[0].clamp(-1.0, 1.0)
         return out.squeeze(0) if single else out
 
 

@@ -123,6 +123,13 @@ int cosim_set_timing(cosim_engine_t* e, int enabled);
 int cosim_profile_step(cosim_engine_t* e, const float* actions_dev, const float* commands_dev, float* state_out_dev,
                        uint8_t* terminated_dev, uint8_t* truncated_dev, double* cycles_out16);
 
+/* Policy side of the loop (reference core/policy.py:11-21, one state per call on the CPU): the actor MLP of an ONNX policy for
+ * all N envs in one launch on the matrix pipe, out = clip(act_L(... act_1(x W_1^T + b_1) ...)).  All pointers are device
+ * pointers; dims[n_layers + 1] (each 1..512); w_dev[l] is [dims[l+1], dims[l]] row-major (Gemm with transB = 1), b_dev[l] may
+ * be NULL; act[l]: 0 none, 1 relu, 2 tanh, 3 elu, 4 sigmoid, 5 leaky relu (act_alpha[l]); clip > 0 clamps to [-clip, clip]. */
+int cosim_mlp_forward(const float* x_dev, int n, int n_layers, const int* dims, const float* const* w_dev, const float* const* b_dev,
+                      const int* act, const float* act_alpha, float clip, float* out_dev, void* stream);
+
 const char* cosim_last_error(void);
 int cosim_model_sizeof(void);
 int cosim_obs_config_sizeof(void);

@@ -726,3 +726,27 @@ def test_two_envs_per_wave_variant_agrees_with_the_default_kernel(parity):
     with pytest.raises((ValueError, RuntimeError)):                      # odd env counts keep the default kernel
         BatchedEnv(cfg, num_envs=3, auto_reset=False).engine.set_param("envs_per_wave", np.array([2.0]))
     a.close(); b.close()
+
+
+@pytest.mark.parametrize("dims,act", [((52, 256, 128, 4), "Elu"), ((88, 512, 256, 128, 8), "Tanh"), ((49, 70, 3), "Relu")])
+def test_fused_mlp_policy_kernel_matches_the_interpreter(tmp_path, dims, act):
+    """cosim_mlp_forward (one MFMA launch for the whole actor) against the operator-by-operator evaluation of the same ONNX
+    file and against numpy, incl. widths that are not multiples of 32 / 4 and batches that do not fill a 32-env tile."""
+    import torch
+    from cosim_amd.policy import MLPPolicy, read_onnx, write_random_mlp
+    p = str(tmp_path / "actor.onnx")
+    write_random_mlp(p, dims[0], dims[-1], hidden=tuple(dims[1:-1]), seed=11, activation=act)
+    fused, ref = MLPPolicy(p, device="cuda:0", fused=True), MLPPolicy(p, device="cuda:0", fused=False)
+    assert fused._fused is not None and ref._fused is None
+    m = read_onnx(p)
+    for n in (1, 37, 4096):
+        x = (2.0 * torch.randn((n, dims[0]), device="cuda:0", generator=torch.Generator(device="cuda:0").manual_seed(n)))
+        a, b = fused.get_action(x), ref.get_action(x)
+        assert a.shape == (n, dims[-1]) and float(a.abs().max()) <= 1.0
+        assert float((a - b).abs().max()) < 2e-5
+    h = x.double().cpu().numpy()
+    for li in range(len(dims) - 1):
+        h = h @ m["init"][f"w{li}"].astype(np.float64).T + m["init"][f"b{li}"]
+        if li < len(dims) - 2:
+            h = {"Elu": lambda v: np.where(v > 0, v, np.exp(np.minimum(v, 0)) - 1), "Tanh": np.tanh, "Relu": lambda v: np.maximum(v, 0)}[act](h)
+    np.testing.assert_allclose(a.cpu().numpy(), np.clip(h, -1, 1), atol=2e-5)
