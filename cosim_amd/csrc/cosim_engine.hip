@@ -354,6 +354,17 @@ int cosim_mlp_forward(const float* x_dev, int n, int n_layers, const int* dims, 
   return COSIM_OK;
 }
 
+int cosim_fleet_stats(const float* info_dev, int n, int info_dim, int nu, const float* cmd_dev, int cmd_stride, int ncmd, double* acc_dev,
+                      void* stream) {
+  if (!info_dev || !acc_dev || n <= 0 || nu < 0 || ncmd < 0 || ncmd > 3 || 4 + nu + ncmd > 32 || info_dim < 4 + nu || (ncmd > 0 && !cmd_dev))
+    return fail(COSIM_EINVAL, "cosim_fleet_stats: bad argument");
+  const int blocks = n >= 8 * 64 ? 64 : (n + 7) / 8;
+  hipLaunchKernelGGL(fleet_stats_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, info_dev, n, info_dim, nu, cmd_dev, cmd_stride, ncmd,
+                     acc_dev);
+  HIP_TRY(hipGetLastError());
+  return COSIM_OK;
+}
+
 const char* cosim_last_error(void) { return g_err.c_str(); }
 int cosim_model_sizeof(void) { return (int)sizeof(cosim_model_t); }
 int cosim_obs_config_sizeof(void) { return (int)sizeof(cosim_obs_config_t); }

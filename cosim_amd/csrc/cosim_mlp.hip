@@ -100,4 +100,32 @@ __global__ __launch_bounds__(256) void mlp_forward_kernel(MlpArgs A) {
   }
 }
 
+// Reporter side of the loop (core/reporter.py:210-218, 429-442, 506-508): count / sum / sum of squares per metric column over
+// the fleet in one launch.  Columns: info[0..4) as they are, |torque| (info[4 .. 4 + nu)), |command_i - measured_i| for
+// i < ncmd (measured = lin_vel_x, lin_vel_y, ang_vel_yaw = info[1 + i]).  acc is [3][K] doubles, K = 4 + nu + ncmd <= 32.
+__global__ __launch_bounds__(256) void fleet_stats_kernel(const float* info, int n, int info_dim, int nu, const float* cmd, int cmd_stride,
+                                                          int ncmd, double* acc) {
+  __shared__ float part[2][8][32];
+  const int K = 4 + nu + ncmd, t = threadIdx.x, c = t & 31, g = t >> 5;
+  float s = 0.f, q = 0.f;
+  if (c < K)
+    for (int r = blockIdx.x * 8 + g; r < n; r += gridDim.x * 8) {
+      const float* row = info + (size_t)r * info_dim;
+      float v;
+      if (c < 4) v = row[c];
+      else if (c < 4 + nu) v = fabsf(row[c]);
+      else { const int i = c - 4 - nu; v = fabsf(cmd[(size_t)r * cmd_stride + i] - row[1 + i]); }
+      s += v; q += v * v;
+    }
+  part[0][g][c] = s; part[1][g][c] = q;
+  __syncthreads();
+  if (t < 32 && t < K) {
+    double ss = 0.0, qq = 0.0;
+    for (int k = 0; k < 8; k++) { ss += (double)part[0][k][t]; qq += (double)part[1][k][t]; }
+    atomicAdd(&acc[K + t], ss);
+    atomicAdd(&acc[2 * K + t], qq);
+    if (blockIdx.x == 0) atomicAdd(&acc[t], (double)n);
+  }
+}
+
 }  // namespace cosim

@@ -26,6 +26,14 @@ class FleetReporter:
         self.trace = []
         self._row = None
         self._fast = hasattr(env, "info_buf") and hasattr(env, "user_command")   # BatchedEnv: the info dict is views of these
+        self._lib = None
+        if self._fast and str(env.device).startswith("cuda") and len(self.names) <= 32:
+            import ctypes
+            from .engine import load_library
+            self._lib = load_library()
+            self._lib.cosim_fleet_stats.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int,
+                                                    ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+            self._lib.cosim_last_error.restype = ctypes.c_char_p
         self.steps = 0
         self.episodes_ended = 0
 
@@ -34,16 +42,24 @@ class FleetReporter:
         nu, cd = self.env.action_dim, min(self.env.command_dim, 3)
         # one row per env: [action_diff_RMSE, lin_vel_x, lin_vel_y, ang_vel_yaw, |torque|..., |command - measured|...]
         # (command tracking as in reporter.py:506-508: applied command 0, 1 vs base linear velocity, 2 vs yaw rate)
-        if self._row is None:
-            self._row = t.empty((self.env.num_envs, len(self.names)), dtype=t.float32, device=self.env.device)
-        base = t.cat([info["action_diff_RMSE"][:, None], info["lin_vel_x"][:, None], info["lin_vel_y"][:, None], info["ang_vel_yaw"][:, None]], dim=1) \
-            if not self._fast else self.env.info_buf[:, :4]
-        self._row[:, :4] = base
-        t.abs(info["torque"], out=self._row[:, 4:4 + nu])
-        if cd:
-            cmd = t.stack([info[f"user_command_{i}"] for i in range(cd)], dim=1) if not self._fast else self.env.user_command[:, :cd]
-            t.abs(cmd - self._row[:, 1:1 + cd], out=self._row[:, 4 + nu:4 + nu + cd])
-        self.acc.update(self._row)
+        if self._fast and self._lib is not None:
+            # BatchedEnv on a GPU: the info dict is views of info_buf / user_command -> one launch of the engine's reducer
+            e = self.env
+            rc = self._lib.cosim_fleet_stats(e.info_buf.data_ptr(), e.num_envs, e.info_buf.shape[1], nu, e.user_command.data_ptr(),
+                                             e.user_command.shape[1], cd, self.acc.buf.data_ptr(),
+                                             t.cuda.current_stream(e.device).cuda_stream)
+            if rc != 0:
+                raise RuntimeError(self._lib.cosim_last_error().decode())
+        else:
+            if self._row is None:
+                self._row = t.empty((self.env.num_envs, len(self.names)), dtype=t.float32, device=self.env.device)
+            self._row[:, :4] = t.cat([info["action_diff_RMSE"][:, None], info["lin_vel_x"][:, None], info["lin_vel_y"][:, None],
+                                      info["ang_vel_yaw"][:, None]], dim=1)
+            t.abs(info["torque"], out=self._row[:, 4:4 + nu])
+            if cd:
+                cmd = t.stack([info[f"user_command_{i}"] for i in range(cd)], dim=1)
+                t.abs(cmd - self._row[:, 1:1 + cd], out=self._row[:, 4 + nu:4 + nu + cd])
+            self.acc.update(self._row)
         self.steps += 1
         if self.trace_env is not None:
             i = self.trace_env

@@ -130,6 +130,12 @@ int cosim_profile_step(cosim_engine_t* e, const float* actions_dev, const float*
 int cosim_mlp_forward(const float* x_dev, int n, int n_layers, const int* dims, const float* const* w_dev, const float* const* b_dev,
                       const int* act, const float* act_alpha, float clip, float* out_dev, void* stream);
 
+/* Reporter side (reference core/reporter.py:210-218 write_info, :429-442, :506-508): fleet statistics of one step's info in one
+ * launch.  acc_dev is double[3][K], K = 4 + nu + ncmd <= 32: count, sum, sum of squares of info[:, 0:4], |info[:, 4:4+nu]| (torque)
+ * and |cmd[:, i] - info[:, 1 + i]| for i < ncmd <= 3 (command tracking); cmd_dev is [N, cmd_stride]. */
+int cosim_fleet_stats(const float* info_dev, int n, int info_dim, int nu, const float* cmd_dev, int cmd_stride, int ncmd, double* acc_dev,
+                      void* stream);
+
 const char* cosim_last_error(void);
 int cosim_model_sizeof(void);
 int cosim_obs_config_sizeof(void);

@@ -750,3 +750,26 @@ def test_fused_mlp_policy_kernel_matches_the_interpreter(tmp_path, dims, act):
         if li < len(dims) - 2:
             h = {"Elu": lambda v: np.where(v > 0, v, np.exp(np.minimum(v, 0)) - 1), "Tanh": np.tanh, "Relu": lambda v: np.maximum(v, 0)}[act](h)
     np.testing.assert_allclose(a.cpu().numpy(), np.clip(h, -1, 1), atol=2e-5)
+
+
+def test_fused_fleet_statistics_match_the_tensor_path():
+    """cosim_fleet_stats (one launch per step) against the same statistics computed with tensor ops from the info dict."""
+    import torch
+    from cosim_amd.batched_env import BatchedEnv
+    from cosim_amd.config import make_config
+    from cosim_amd.reporter import FleetReporter
+    env = BatchedEnv(make_config("flamingo_light_v1", num_envs=300, seed=2), num_envs=300, seed=2, auto_reset=True)
+    fast, slow = FleetReporter(env), FleetReporter(env)
+    assert fast._lib is not None
+    slow._lib = None                                                  # forces the tensor path
+    env.reset()
+    env.receive_user_command(np.array([0.5, -0.2, 0.3, 0.0], dtype=np.float32))
+    g = torch.Generator(device=env.device).manual_seed(0)
+    for t in range(25):
+        _, _, _, info = env.step(0.3 * torch.randn((300, 4), device=env.device, generator=g))
+        fast.write_info(info); slow.write_info(info)
+    a, b = fast.summary()["metrics"], slow.summary()["metrics"]
+    assert set(a) == set(b) and a["lin_vel_x"]["count"] == 300 * 25
+    for k in a:
+        assert a[k]["mean"] == pytest.approx(b[k]["mean"], rel=1e-5, abs=1e-7) and a[k]["std"] == pytest.approx(b[k]["std"], rel=1e-4, abs=1e-6), k
+    env.close()
