@@ -116,8 +116,10 @@ def cpu_baseline(sample_envs=16, sample_steps=12000):
     except Exception as e:  # noqa: BLE001
         ref = f"reference MuJoCo CPU path unavailable on this host ({type(e).__name__})"
     return {"value": n_steps / t_total, "unit": "env-steps/s", "cores": 1, "kind": "port",
-            "sample": f"{sample_envs} envs x {sample_steps} control steps of {ROBOT} flat, sinusoid actions, fp64 oracle, "
-                      f"1 thread of {os.cpu_count()} host cores ({t_total:.1f} s); {ref}",
+            "sample": f"{sample_envs} envs x {sample_steps} control steps of {ROBOT} flat, fp64 oracle, 1 thread of {os.cpu_count()} host "
+                      f"cores ({t_total:.1f} s); same sinusoid drive (amplitude, frequency) and init noise as the GPU leg but NOT the same "
+                      "draws (numpy default_rng phases instead of the Philox phases), nominal masses and PD gains, no action delay and "
+                      f"no sensor noise (the oracle steps the physics; the wrapper layer is not in this leg); {ref}",
             "threads": {"value": done / t_mt, "cores": nthr, "sample": f"{nthr} threads x 1 env x {mt_steps} control steps ({t_mt:.1f} s)"},
             **({"reference": ref_leg} if ref_leg else {})}
 
@@ -146,7 +148,55 @@ def pmc_traffic(workload):
                             "scratch, ~76 B/lane x 262144 lanes)"}
 
 
-def main():
+def free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def relaunch_command(argv, n_ranks, port):
+    """The torch.distributed.run command that re-runs this script as `n_ranks` ranks of one node (one process per GPU)."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_ranks}", "--master-addr", "127.0.0.1",
+            "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def self_launch(args, argv):
+    """`python bench.py --gpus N` with N > 1 and no torchrun environment: start the N ranks as child processes and pass their
+    output and exit code on.  Runs before anything in this process touches the GPU (no HIP call, no torch.cuda query): the
+    parent only waits."""
+    import subprocess
+    cmd = relaunch_command(argv, args.gpus, free_port())
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    return subprocess.call(cmd, env=env)
+
+
+def launch_selftest(args):
+    """--selftest-launch: the rendezvous / barrier / max-over-ranks / rank-0-prints skeleton of the bench with no GPU work
+    (CPU test of the launcher: tests/test_distributed.py)."""
+    import torch
+    import torch.distributed as dist
+    from cosim_amd.distributed import MetricsAccumulator, init_from_env
+    rank, world = init_from_env("gloo")
+    acc = MetricsAccumulator(["x"])
+    acc.update(torch.full((4, 1), float(rank + 1), dtype=torch.float64))
+    out = acc.reduce()
+    t = torch.tensor([float(rank)], dtype=torch.float64)
+    if world > 1:
+        dist.barrier()
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    if rank == 0:
+        print(json.dumps({"launcher_selftest": True, "n_gpus": world, "max_rank": float(t.item()), "count": out["x"]["count"],
+                          "mean": out["x"]["mean"]}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1000)
@@ -159,18 +209,24 @@ def main():
                          "steps: one shard's next launch fills the tail of the others'); default 1 = one launch per fleet step")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse ranks on one GPU)")
     ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses cuda:0 (with --backend gloo)")
-    args = ap.parse_args()
+    ap.add_argument("--report-every", type=int, default=16, help="reporter statistics are sampled every this many timed steps")
+    ap.add_argument("--selftest-launch", action="store_true", help="launcher / collective skeleton only, no GPU work (CPU test)")
+    args = ap.parse_args(argv)
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args, argv))     # the children are the ranks; this process never touches the GPU
+    if args.selftest_launch:
+        return launch_selftest(args)
 
     import torch
     import torch.distributed as dist
     from cosim_amd.batched_env import BatchedEnv
     from cosim_amd.config import make_config
-    from cosim_amd.distributed import MetricsAccumulator, init_from_env
+    from cosim_amd.distributed import init_from_env
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if args.gpus != 1:
-            raise SystemExit(f"--gpus {args.gpus} needs a torch.distributed.run launch with {args.gpus} ranks (WORLD_SIZE={world})")
+        raise SystemExit(f"--gpus {args.gpus} but the launcher started {world} rank(s) (WORLD_SIZE): the two must agree")
     rank, world = init_from_env(args.backend)
     local = 0 if args.single_device else int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local)
@@ -191,7 +247,10 @@ def main():
     nu = env.action_dim
     total_steps = args.warmup + args.steps
     actions = [synthetic_actions(ns, env_id0 + i * ns, total_steps, nu, env.device) for i in range(S)]
-    metrics = MetricsAccumulator(["action_diff_RMSE", "lin_vel_x", "lin_vel_y", "ang_vel_yaw"], device=env.device)
+    # reporter statistics (core/reporter.py's per-step scalars over the fleet): one launch of the fused reducer per sampled
+    # step and shard, sufficient statistics stay on the device until the one all-reduce that closes the timed region
+    from cosim_amd.reporter import FleetReporter
+    reporters = [FleetReporter(e) for e in envs]
     for i, e in enumerate(envs):
         with torch.cuda.stream(streams[i]):
             e.receive_user_command(np.array([0.5, 0.0, 0.0, 0.0], dtype=np.float32))
@@ -199,9 +258,11 @@ def main():
             for t in range(args.warmup):
                 e.step(actions[i][t])
     torch.cuda.synchronize()
-    metrics.update(env.info_buf[:, :4])   # warm-up of the torch reduction kernels (first use loads code objects: ~100 ms)
-    metrics.reduce()
-    metrics.buf.zero_()
+    for r in reporters:                   # warm-up of the reducer and of the torch kernels behind reduce() (first use loads code
+        r.write_info(None)                # objects: ~100 ms), then start from zero
+        r.acc.reduce()
+        r.acc.buf.zero_()
+    torch.cuda.synchronize()
     for e in envs:
         e.engine.set_timing(True)
 
@@ -217,10 +278,12 @@ def main():
         for i, e in enumerate(envs):
             with torch.cuda.stream(streams[i]):
                 state, term, trunc, info = e.step(actions[i][t])
-                if (t & 63) == 0:
-                    metrics.update(e.info_buf[:, :4])  # reporter statistics, sampled off the critical path
+                if (t - args.warmup) % args.report_every == 0:
+                    reporters[i].write_info(info)       # reporter statistics of this step (sampled: first timed step, then every k-th)
     torch.cuda.synchronize()
-    fleet = metrics.reduce()                            # the one collective: RCCL all-reduce of (count, sum, sum^2)
+    for r in reporters[1:]:
+        reporters[0].acc.buf += r.acc.buf
+    fleet = reporters[0].acc.reduce()                   # the one collective: RCCL all-reduce of (count, sum, sum^2)
     sync()
     dt = time.perf_counter() - t0
     kt = [e.engine.kernel_time() for e in envs]
@@ -251,6 +314,7 @@ def main():
                        "envs_per_gpu": n, "global_envs": world * n, "substeps_per_s": value * 4, "parallelism": f"shard{world}",
                        "streams_per_gpu": S, "envs_per_launch": ns,
                        "finite": finite, "fleet_action_diff_RMSE": fleet["action_diff_RMSE"]["mean"],
+                       "fleet_samples": fleet["action_diff_RMSE"]["count"], "fleet_abs_torque_0": fleet["abs_torque_0"]["mean"],
                        "solver_per_substep": {"rows": st["rows"] / nsub, "newton_iters": st["newton_iters"] / nsub,
                                               "ls_evals": st["ls_evals"] / nsub, "factorisations": st["factorisations"] / nsub},
                        "nan_resets": st["nan_resets"]},

@@ -147,15 +147,18 @@ class BatchedEnv:
         self.engine.set_param("body_invweight0", c["body_invweight0"][:, :, 0])
         self.engine.set_param("dof_invweight0", c["dof_invweight0"])
         self.engine.set_param("meaninertia", c["meaninertia"])
+        nu = blob.nu
+        self.kp = np.tile(np.array(get_field(blob, "ctl_kp")[:nu]), (N, 1))
+        self.kd = np.tile(np.array(get_field(blob, "ctl_kd")[:nu]), (N, 1))
         if gain_noise > 0:
-            nu = blob.nu
-            kp = np.tile(np.array(get_field(blob, "ctl_kp")[:nu]), (N, 1))
-            kd = np.tile(np.array(get_field(blob, "ctl_kd")[:nu]), (N, 1))
+            kp, kd = self.kp, self.kd
             idx = np.arange(nu)[None, :]
             up = crng.uniform(self.seed, gids[:, None], 0, crng.PURPOSE_GAIN, idx)
             ud = crng.uniform(self.seed, gids[:, None], 1, crng.PURPOSE_GAIN, idx)
-            self.engine.set_param("kp", kp * (1.0 + gain_noise * (2.0 * up - 1.0)))
-            self.engine.set_param("kd", kd * (1.0 + gain_noise * (2.0 * ud - 1.0)))
+            self.kp = kp * (1.0 + gain_noise * (2.0 * up - 1.0))
+            self.kd = kd * (1.0 + gain_noise * (2.0 * ud - 1.0))
+            self.engine.set_param("kp", self.kp)
+            self.engine.set_param("kd", self.kd)
 
     # ------------------------------------------------------------------ BaseEnv API (wrappers.py:8-85), batched
     def _stream(self):
@@ -249,12 +252,16 @@ class BatchedEnv:
         """Cumulative solver counters since creation (fleet sums): control steps, constraint rows (summed over
         substeps), Newton iterations, line-search evaluations, Hessian factorisations, non-finite resets."""
         t = self.torch
-        buf = t.zeros((self.num_envs, 8), dtype=t.float32, device=self.device)
+        buf = t.zeros((self.num_envs, 12), dtype=t.float32, device=self.device)
         self.engine.get("meta", buf.data_ptr(), self._stream())
         t.cuda.synchronize(self.device)
-        m = buf.view(t.int32).to(t.int64).sum(dim=0).cpu().numpy()
+        mi = buf.view(t.int32).to(t.int64)
+        m = mi.sum(dim=0).cpu().numpy()
+        # dropped_*: contacts / limit rows that found no slot (0 unless an env was stepped with a truncated constraint set);
+        # max_contacts: most contacts detected in one substep by any env of the fleet
         return {"step_count": int(m[1]), "rows": int(m[3]), "nan_resets": int(m[4]), "newton_iters": int(m[5]),
-                "ls_evals": int(m[6]), "factorisations": int(m[7])}
+                "ls_evals": int(m[6]), "factorisations": int(m[7]), "dropped_contacts": int(m[8]), "dropped_limit_rows": int(m[9]),
+                "max_contacts": int(mi[:, 10].max().item()), "episodes_ended": int(m[11])}
 
     def render(self):
         pass  # headless

@@ -62,6 +62,11 @@ def main(argv=None) -> int:
             write_random_mlp(path, env.state_dim, env.action_dim, seed=args.seed)
         pc = {"policy": {"use_lstm": bool(args.lstm), "h_in_dim": args.hidden_dim, "c_in_dim": args.hidden_dim}}
         policy = build_policy(pc, path, num_envs=env.num_envs, device=env.device)
+    if args.graph and not getattr(policy, "graph_safe", False):
+        ap.error("--graph needs an ONNX policy (random-mlp or a file): the sinusoid drive keeps its clock on the host, a captured "
+                 "graph would replay one frozen action")
+    if args.graph and (args.push_at >= 0 or args.trace_env >= 0):
+        ap.error("--graph replays one captured control step: --push-at and --trace-env need the eager loop")
     rep = FleetReporter(env, trace_env=args.trace_env if args.trace_env >= 0 else None)
     run = Runner(env, policy, reporter=rep)
     for i, v in enumerate(args.command[:env.command_dim]):

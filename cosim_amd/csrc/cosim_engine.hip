@@ -284,7 +284,7 @@ static void build_layout(cosim_engine* e) {
   L.s_warm = o; o += m.nv;
   L.s_delay = o; o += m.nu;
   L.s_lastact = o; o += m.nu;
-  L.s_meta = o; o += 8;
+  L.s_meta = o; o += Layout::NMETA;
   L.s_cache = o; o += e->ho.frame_dim;
   L.s_stack = o; o += e->ho.stack_size * e->ho.stacked_dim;
   L.s_stride = round_up(o, 32);
@@ -590,7 +590,7 @@ static int locate(cosim_engine* e, const std::string& n, int* off, int* width) {
   if (n == "qpos") { *off = e->lay.s_qpos; *width = e->model.nq; }
   else if (n == "qvel") { *off = e->lay.s_qvel; *width = e->model.nv; }
   else if (n == "qacc_warmstart") { *off = e->lay.s_warm; *width = e->model.nv; }
-  else if (n == "meta") { *off = e->lay.s_meta; *width = 8; }
+  else if (n == "meta") { *off = e->lay.s_meta; *width = Layout::NMETA; }
   else return fail(COSIM_EINVAL, "unknown state field " + n);
   return COSIM_OK;
 }

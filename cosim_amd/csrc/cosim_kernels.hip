@@ -182,7 +182,8 @@ __device__ __forceinline__ void make_frame(const float* n, float* t1, float* t2)
   cross(t2, n, t1);
 }
 
-// Philox4x32-10, counter-based: key = (seed, global env id), counter = (step, purpose, index, 0); first output word
+// Philox4x32-10, counter-based: key = (seed_lo, seed_hi), counter = (step, purpose | index << 8, gid_lo, gid_hi); first output
+// word.  Seed and env id in separate words: two seeds give independent fleets, not permutations of one another.
 __device__ __forceinline__ unsigned philox_first(unsigned k0, unsigned k1, unsigned c0, unsigned c1, unsigned c2, unsigned c3) {
 #pragma unroll
   for (int r = 0; r < 10; r++) {
@@ -462,7 +463,7 @@ __global__ __launch_bounds__(64, (RPL == 1 && EPW == 1 && !HF) ? 4 : ((EPW == 1 
   const unsigned step_count = (unsigned)meta[1];
   int has_prev = meta[2];
   const unsigned long long gid = (unsigned long long)(A.env_id0 + env);
-  const unsigned k0 = A.seed_lo ^ (unsigned)gid, k1 = A.seed_hi ^ (unsigned)(gid >> 32);
+  const unsigned k0 = A.seed_lo, k1 = A.seed_hi, g0 = (unsigned)gid, g1 = (unsigned)(gid >> 32);
 
   bool do_reset = false;
   if (A.mode == MODE_RESET) {
@@ -494,6 +495,7 @@ __global__ __launch_bounds__(64, (RPL == 1 && EPW == 1 && !HF) ? 4 : ((EPW == 1 
   if (lane < 10) S.sens[lane] = lane == 0 ? 1.f : 0.f;
   int terminated = 0, truncated = 0, bad = 0;
   int st_newton = 0, st_ls = 0, st_build = 0, st_rows = 0;  // solver statistics of this control step
+  int st_dropcon = 0, st_droplim = 0, st_maxcon = 0;          // capacity: contacts / limit rows left out, most contacts seen in one substep
 
   if (A.mode != MODE_RESET) {
     // ---- state -> LDS
@@ -503,7 +505,7 @@ __global__ __launch_bounds__(64, (RPL == 1 && EPW == 1 && !HF) ? 4 : ((EPW == 1 
 
     // ---- control (once per control step): delay filter + PD, zero-order hold over the substeps
     if (A.mode == MODE_STEP) {
-      const bool delayed = (ob.action_delay_prob > u01(philox_first(k0, k1, step_count, 0u, 0u, 0u))) && has_prev;  // control_manager.py:15-23
+      const bool delayed = (ob.action_delay_prob > u01(philox_first(k0, k1, step_count, 0u, g0, g1))) && has_prev;  // control_manager.py:15-23
       if (lane < nu) {
         const LaneRec& R = dm.rec[lane];
         const float raw_action = A.actions[(size_t)env * nu + lane];
@@ -1137,16 +1139,22 @@ __global__ __launch_bounds__(64, (RPL == 1 && EPW == 1 && !HF) ? 4 : ((EPW == 1 
         unsigned long long ml = grp_ballot<LW>(lo_v, hb), mh = grp_ballot<LW>(hi_v, hb);
         int rlo = __popcll(ml & lanemask_lt(ln)), rhi = __popcll(ml) + __popcll(mh & lanemask_lt(ln));
         nl = __popcll(ml) + __popcll(mh);
-        if (nl > L::NLIM) nl = L::NLIM;
+        if (nl > L::NLIM) { st_droplim += nl - L::NLIM; nl = L::NLIM; }
         if (lo_v && rlo < L::NLIM) { S.lim_body[rlo] = ln; S.lim_sign[rlo] = 1.f; S.lim_dist[rlo] = dlo; }
         if (hi_v && rhi < L::NLIM) { S.lim_body[rhi] = ln; S.lim_sign[rhi] = -1.f; S.lim_dist[rhi] = dhi; }
       }
       {
+        // capacity (MuJoCo's arena holds every contact; here the slots are sized per kernel variant): whatever does not fit is
+        // left out in detection order AND counted -- meta[8] / solver_stats()["dropped_contacts"] is non-zero whenever an env
+        // was stepped with a truncated constraint set
+        const int ncon_all = ncon;
         int room = (MAXROWS - ne - nf - nl) / 4;
         if (room < 0) room = 0;
         if (ncon > room) ncon = room;
         if (ncon > MC) ncon = MC;
         if (ne + 4 * ncon > NGENMAX) ncon = (NGENMAX - ne) / 4;
+        st_dropcon += ncon_all - ncon;
+        st_maxcon = max(st_maxcon, ncon_all);
       }
       const int ngen = ne + 4 * ncon;       // general rows (dense J): equality + contact
       const int nefc = ngen + nf + nl;      // then unit rows: frictionloss, limits
@@ -1698,6 +1706,27 @@ __global__ __launch_bounds__(64, (RPL == 1 && EPW == 1 && !HF) ? 4 : ((EPW == 1 
     do_reset = bad || ((terminated || truncated) && ob.auto_reset);
   }
 
+  // =============================================================== info / flags (_get_info, flamingo_light_v1.py:166-183)
+  // Written from the state the step ended in, BEFORE an auto-reset touches it: on the step that ends an episode the reference's
+  // info describes that last step (the returned state vector, as in gym-style auto-reset, is the first one of the next episode).
+  if (A.mode == MODE_STEP) {
+    WSYNC();
+    if (A.info != nullptr) {
+      float* inf = A.info + (size_t)env * ob.info_dim;
+      const float raw_action = lane < nu ? S.act[lane] : 0.f;
+      const float prev_action = lane < nu ? rec[lay.s_lastact + lane] : 0.f;   // still the previous step's action (zeros after a reset)
+      float dsq = lane < nu ? (raw_action - prev_action) * (raw_action - prev_action) : 0.f;
+      float rmse = sqrtf(grp_sum<LW>(dsq) / (float)nu);
+      if (lane == 0) { inf[0] = rmse; inf[1] = S.sens[7]; inf[2] = S.sens[8]; inf[3] = S.sens[6]; }
+      if (lane < nu) { inf[4 + lane] = S.tq[lane]; inf[4 + nu + lane] = raw_action * dm.rec[lane].a_scale; }
+      if (lane < dm.ninfo_state) {
+        const LaneRec& R = dm.rec[lane];
+        inf[4 + 2 * nu + lane] = (R.i_kind == 0 ? S.qpos[R.i_adr] : S.qvel[R.i_adr]) * R.i_gear;
+      }
+    }
+    if (lane == 0) { A.terminated[env] = (uint8_t)terminated; A.truncated[env] = (uint8_t)truncated; }
+  }
+
   // =============================================================== reset_model (flamingo_light_v1.py:209-232)
   int nan_resets = meta[4];
   if (bad) nan_resets++;
@@ -1706,7 +1735,7 @@ __global__ __launch_bounds__(64, (RPL == 1 && EPW == 1 && !HF) ? 4 : ((EPW == 1 
     if (lane < NV) { S.qvel[lane] = 0.f; S.qacc[lane] = 0.f; }
     WSYNC();
     if (lane < dm.init_noise_nq)
-      S.qpos[dm.rec[lane].n_qadr] += ob.init_noise * (2.f * u01(philox_first(k0, k1, step_count, 2u, (unsigned)lane, 0u)) - 1.f);
+      S.qpos[dm.rec[lane].n_qadr] += ob.init_noise * (2.f * u01(philox_first(k0, k1, step_count, 2u | ((unsigned)lane << 8), g0, g1)) - 1.f);
     WSYNC();
     // sensors of the mj_forward at the reset state: zero velocity, IMU orientation from the base quaternion
     {
@@ -1768,7 +1797,7 @@ __global__ __launch_bounds__(64, (RPL == 1 && EPW == 1 && !HF) ? 4 : ((EPW == 1 
         // truncated Gaussian by inverse CDF (scipy.stats.truncnorm.rvs, noise_generator_utils.py:22-28)
         const float mean = ob.noise_mean[f], sd_ = ob.noise_std[f];
         const float ca = ob.noise_ca[f], cb = ob.noise_cb[f];
-        float z = normcdfinvf(ca + u01(philox_first(k0, k1, step_count, 1u, (unsigned)e, 0u)) * (cb - ca));
+        float z = normcdfinvf(ca + u01(philox_first(k0, k1, step_count, 1u | ((unsigned)e << 8), g0, g1)) * (cb - ca));
         float nz = fminf(ob.noise_upper[f], fmaxf(ob.noise_lower[f], mean + sd_ * z));
         val += nz;
       }
@@ -1795,23 +1824,7 @@ __global__ __launch_bounds__(64, (RPL == 1 && EPW == 1 && !HF) ? 4 : ((EPW == 1 
     }
   }
 
-  // =============================================================== info / flags / state write-back
-  if (A.mode == MODE_STEP) {
-    if (A.info != nullptr) {
-      float* inf = A.info + (size_t)env * ob.info_dim;
-      const float raw_action = lane < nu ? S.act[lane] : 0.f;
-      const float prev_action = (lane < nu && !do_reset) ? rec[lay.s_lastact + lane] : 0.f;   // still the previous step's action
-      float dsq = lane < nu ? (raw_action - prev_action) * (raw_action - prev_action) : 0.f;
-      float rmse = sqrtf(grp_sum<LW>(dsq) / (float)nu);
-      if (lane == 0) { inf[0] = rmse; inf[1] = S.sens[7]; inf[2] = S.sens[8]; inf[3] = S.sens[6]; }
-      if (lane < nu) { inf[4 + lane] = S.tq[lane]; inf[4 + nu + lane] = raw_action * dm.rec[lane].a_scale; }
-      if (lane < dm.ninfo_state) {
-        const LaneRec& R = dm.rec[lane];
-        inf[4 + 2 * nu + lane] = (R.i_kind == 0 ? S.qpos[R.i_adr] : S.qvel[R.i_adr]) * R.i_gear;
-      }
-    }
-    if (lane == 0) { A.terminated[env] = (uint8_t)terminated; A.truncated[env] = (uint8_t)truncated; }
-  }
+  // =============================================================== state write-back
   STAMP(9);   // observation build + info
   if (PROF && A.dbg != nullptr && wlane == 0)
     for (int i = 0; i < 16; i++) atomicAdd(reinterpret_cast<unsigned long long*>(A.dbg) + i, pacc[i]);
@@ -1821,6 +1834,8 @@ __global__ __launch_bounds__(64, (RPL == 1 && EPW == 1 && !HF) ? 4 : ((EPW == 1 
   if (lane == 0) {
     meta[0] = sim_step; meta[1] = (int)(step_count + 1u); meta[2] = has_prev; meta[4] = nan_resets;
     meta[5] += st_newton; meta[6] += st_ls; meta[7] += st_build; meta[3] += st_rows;
+    meta[8] += st_dropcon; meta[9] += st_droplim; meta[10] = max(meta[10], st_maxcon);
+    if (A.mode == MODE_STEP && (terminated || truncated)) meta[11] += 1;   // episodes ended (device-side count: survives graph replay)
   }
 }
 

@@ -44,15 +44,17 @@ class ObsConfig(ctypes.Structure):
 
 def build_library(force: bool = False, verbose: bool = False) -> str:
     """Compile the HIP engine for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
-    srcs = [os.path.join(CSRC, f) for f in ("cosim_engine.hip", "cosim_kernels.hip", "cosim_dev.h")]
-    hdrs = [os.path.join(_DIR, "..", "include", f) for f in ("cosim.h", "cosim_model.h")]
+    # every file the translation unit pulls in (cosim_engine.hip includes the other .hip / .h files of csrc/)
+    inc = os.path.join(_DIR, "..", "include")
+    deps = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith((".hip", ".h"))]
+    deps += [os.path.join(inc, f) for f in sorted(os.listdir(inc)) if f.endswith(".h")]
     if not force and os.path.isfile(LIB_PATH):
-        newest = max(os.path.getmtime(p) for p in srcs + hdrs)
+        newest = max(os.path.getmtime(p) for p in deps)
         if os.path.getmtime(LIB_PATH) >= newest:
             return LIB_PATH
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value",
-           "-o", LIB_PATH, srcs[0]]
+           "-o", LIB_PATH, os.path.join(CSRC, "cosim_engine.hip")]
     if verbose:
         cmd.append("-Rpass-analysis=kernel-resource-usage")
     subprocess.check_call(cmd)

@@ -326,6 +326,8 @@ class MLPPolicy:
                 alpha=(ctypes.c_float * nl)(*[al for *_, al in chain]),
                 out_dim=chain[-1][0].shape[0], in_dim=chain[0][0].shape[1], out=None)
 
+    graph_safe = True     # stateless: get_action is pure device work
+
     def get_action(self, state):
         t = self.torch
         s = t.as_tensor(state, dtype=t.float32, device=self.device)
@@ -361,21 +363,26 @@ class LSTMPolicy:
         self.h_in = torch.zeros((1, num_envs, config["policy"]["h_in_dim"]), dtype=torch.float32, device=self.device)
         self.c_in = torch.zeros((1, num_envs, config["policy"]["c_in_dim"]), dtype=torch.float32, device=self.device)
 
+    graph_safe = True     # get_action is pure device work on persistent tensors (Runner.test_graphed)
+
     def reset(self, mask=None):
-        """Zero the recurrent state (of the masked envs): what re-creating the policy does in the reference."""
+        """Zero the recurrent state (of the masked envs): what re-creating the policy does in the reference
+        (core/tester.py builds a fresh policy per episode).  Branch-free on the device, so it can sit inside a captured graph."""
         if mask is None:
             self.h_in.zero_(); self.c_in.zero_()
         else:
-            m = self.torch.as_tensor(mask, device=self.device).bool()
-            self.h_in[:, m] = 0
-            self.c_in[:, m] = 0
+            keep = (self.torch.as_tensor(mask, device=self.device) == 0).to(self.h_in.dtype)[None, :, None]
+            self.h_in.mul_(keep)
+            self.c_in.mul_(keep)
 
     def get_action(self, state):
         t = self.torch
         s = t.as_tensor(state, dtype=t.float32, device=self.device)
         single = s.dim() == 1
         action, h_out, c_out = self.graph.run({self.input_name: s.unsqueeze(0) if single else s, "h_in": self.h_in, "c_in": self.c_in})[:3]
-        self.h_in, self.c_in = h_out, c_out
+        # in place: the recurrent state lives in two persistent tensors, so a HIP-graph replay of this call feeds it back
+        self.h_in.copy_(h_out.reshape(self.h_in.shape))
+        self.c_in.copy_(c_out.reshape(self.c_in.shape))
         action = action.reshape(-1, action.shape[-1]).clamp(-1.0, 1.0)
         return action.squeeze(0) if single else action
 

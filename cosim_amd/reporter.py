@@ -37,7 +37,9 @@ class FleetReporter:
         self.steps = 0
         self.episodes_ended = 0
 
-    def write_info(self, info: dict):
+    def write_info(self, info):
+        """``info``: the dict of ``BatchedEnv.step`` (on the GPU fast path it is only a token: the statistics are reduced from
+        the env's own ``info_buf`` / ``user_command`` buffers, which the dict's entries are views of)."""
         t = self.env.torch
         nu, cd = self.env.action_dim, min(self.env.command_dim, 3)
         # one row per env: [action_diff_RMSE, lin_vel_x, lin_vel_y, ang_vel_yaw, |torque|..., |command - measured|...]

@@ -4,6 +4,9 @@ The reference never seeds ``random`` / ``numpy.random``, so "same
 meaning there; the engine defines its own streams instead.  Every draw is a pure function of
 ``(seed, global env id, step counter, purpose, index)``, which makes results independent of how
 environments are sharded over GPUs and lets the tests predict device draws on the host.
+Seed and env id sit in separate Philox words -- key = (seed_lo, seed_hi), counter = (step,
+purpose | index << 8, gid_lo, gid_hi) -- so fleets drawn under two seeds are independent samples
+(with key = seed ^ gid, seed s' merely permuted the envs of seed s).
 
 Device twin: ``philox()`` / ``u01()`` in ``csrc/cosim_kernels.hip``.
 Purposes: 0 action-delay draw, 1 sensor noise (index = frame element), 2 init-qpos noise
@@ -42,15 +45,21 @@ def u01(x):
     return ((x >> np.uint32(8)).astype(np.float32) * np.float32(1.0 / 16777216.0) + np.float32(0.5 / 16777216.0)).astype(np.float32)
 
 
-def env_keys(seed: int, env_ids):
+def seed_key(seed: int):
+    """Philox key words of a 64-bit seed."""
+    return np.uint32(seed & 0xFFFFFFFF), np.uint32((seed >> 32) & 0xFFFFFFFF)
+
+
+def env_words(env_ids):
+    """Counter words 2 and 3: low / high half of the global env id."""
     gid = np.asarray(env_ids, dtype=np.uint64)
-    k0 = np.uint32(seed & 0xFFFFFFFF) ^ (gid & MASK32).astype(np.uint32)
-    k1 = np.uint32((seed >> 32) & 0xFFFFFFFF) ^ (gid >> np.uint64(32)).astype(np.uint32)
-    return k0, k1
+    return (gid & MASK32).astype(np.uint32), (gid >> np.uint64(32)).astype(np.uint32)
 
 
 def uniform(seed: int, env_ids, step, purpose: int, index):
     """First output word of the stream as float32 uniform in (0,1); shape = broadcast(env_ids, step, index)."""
-    k0, k1 = env_keys(seed, env_ids)
-    c0, _, _, _ = philox4x32(k0, k1, np.asarray(step, dtype=np.uint32), np.uint32(purpose), np.asarray(index, dtype=np.uint32), np.uint32(0))
+    k0, k1 = seed_key(seed)
+    g0, g1 = env_words(env_ids)
+    c1 = np.uint32(purpose) | (np.asarray(index, dtype=np.uint32) << np.uint32(8))
+    c0, _, _, _ = philox4x32(k0, k1, np.asarray(step, dtype=np.uint32), c1, g0, g1)
     return u01(c0)

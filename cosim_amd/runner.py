@@ -75,6 +75,8 @@ class Runner:
             if self._push_event:
                 env.event("push", self._push_vel)                  # :80-81
             state, terminated, truncated, info = env.step(action)  # :90
+            if env.auto_reset and hasattr(self.policy, "reset"):
+                self.policy.reset(terminated | truncated)          # the reference builds a fresh policy per episode (tester.py:57-60)
             if self.reporter is not None:
                 self.reporter.write_info(self._one_env_info(info, self.report_env) if self.report_env is not None else info)
             if on_step is not None:
@@ -97,13 +99,21 @@ class Runner:
         env, t = self.env, self.env.torch
         if not env.auto_reset:
             raise ValueError("test_graphed needs auto_reset=True (no per-step host check of the done flags)")
+        if not getattr(self.policy, "graph_safe", False):
+            raise ValueError(f"test_graphed: {type(self.policy).__name__}.get_action is not pure device work on persistent tensors "
+                             "(a host-side clock or state would be frozen into the captured graph); use an ONNX policy "
+                             "(policy.MLPPolicy / policy.LSTMPolicy) or the eager Runner.test loop")
+        if self.reporter is not None and getattr(self.reporter, "trace_env", None) is not None:
+            raise ValueError("test_graphed: a reporter with trace_env reads the device every step; use Runner.test")
         state, _ = env.reset()
         env.receive_user_command(self.user_command)
         action = t.zeros((env.num_envs, env.action_dim), dtype=t.float32, device=env.device)
 
         def one_step():
             action.copy_(self.policy.get_action(env.state))
-            _, _, _, info = env.step(action)
+            _, terminated, truncated, info = env.step(action)
+            if hasattr(self.policy, "reset"):
+                self.policy.reset(terminated | truncated)          # device-side mask: replayed with the graph
             if self.reporter is not None:
                 self.reporter.write_info(info)
         side = t.cuda.Stream(device=env.device)
@@ -125,4 +135,6 @@ class Runner:
             steps += 1
         if self.reporter is not None and hasattr(self.reporter, "steps"):
             self.reporter.steps = steps          # write_info ran once per replay on the device, once in Python
+        if self.reporter is not None and hasattr(self.reporter, "episodes_ended"):
+            self.reporter.episodes_ended = env.solver_stats()["episodes_ended"]   # counted on the device (meta[11]), graph or not
         return steps

@@ -159,3 +159,90 @@ class WrapperOracle:
         state = self._build(obs, reset=False)
         truncated = self.sim_step == self.max_sim_step
         return state, terminated, truncated
+
+
+# --------------------------------------------------------------------------------------------- robot-env layer, per robot
+# `_get_obs` / `_get_info` / `initial_qpos` of the four robot envs restated over an oracle's (qpos, qvel, sensors).  The joint
+# name lists are the reference's own; addresses follow MuJoCo's document order (one free joint, then one hinge per joint
+# element: qpos address 7 + k, dof address 6 + k for the k-th hinge), read from the MJCF text -- not from cosim_amd.compile.
+_W4_LEGS = ("FL", "FR", "RL", "RR")
+ROBOT_ENV = {
+    # flamingo_light_v1.py:95-98,171,229 (no gear; info state = [dof_pos[0], dof_pos[1], dof_vel[2], dof_vel[3]])
+    "flamingo_light_v1": dict(
+        qpos_names=["left_shoulder_joint", "right_shoulder_joint"],
+        qvel_names=["left_shoulder_joint", "right_shoulder_joint", "left_wheel_joint", "right_wheel_joint"],
+        geared=slice(0, 0), gear=1.0, info_state=[("pos", 0), ("pos", 1), ("vel", 2), ("vel", 3)],
+        init_height=0.13, init_noise=["left_shoulder_joint", "right_shoulder_joint", "left_wheel_joint", "right_wheel_joint"],
+        action_scale=lambda hw: [hw["action_scales"]["shoulder"]] * 2 + [hw["action_scales"]["wheel"]] * 2),
+    # flamingo_p_v3.py:107-120 (dof_pos[4:6], dof_vel[4:6] times gear_ratio), :207 (info state ungeared), :248-254
+    "flamingo_p_v3": dict(
+        qpos_names=["left_hip_joint", "right_hip_joint", "left_shoulder_joint", "right_shoulder_joint", "left_leg_joint", "right_leg_joint"],
+        qvel_names=["left_hip_joint", "right_hip_joint", "left_shoulder_joint", "right_shoulder_joint", "left_leg_joint", "right_leg_joint",
+                    "left_wheel_joint", "right_wheel_joint"],
+        geared=slice(4, 6), gear="gear_ratio", info_state=[("pos", i) for i in range(6)] + [("vel", 6), ("vel", 7)],
+        init_height=0.61282, init_noise="all",
+        action_scale=lambda hw: [hw["action_scales"][k] for k in ("hip", "hip", "shoulder", "shoulder", "leg", "leg", "wheel", "wheel")]),
+    # w4_p_v2.py:107-120 (dof_pos[8:12], dof_vel[8:12] times gear_ratio), :204-206, :243-249
+    "w4_p_v2": dict(
+        qpos_names=[f"{l}_{n}_joint" for n in ("hip", "shoulder", "leg") for l in _W4_LEGS],
+        qvel_names=[f"{l}_{n}_joint" for n in ("hip", "shoulder", "leg", "wheel") for l in _W4_LEGS],
+        geared=slice(8, 12), gear="gear_ratio", info_state=[("pos", i) for i in range(12)] + [("vel", i) for i in range(12, 16)],
+        init_height=0.47957, init_noise="all",
+        action_scale=lambda hw: [hw["action_scales"][n] for n in ("hip", "shoulder", "leg", "wheel") for _ in _W4_LEGS]),
+    # humanoid_p_v0.py:139-153 (joint_names_in_order), :268 (info state = dof_pos), :305-311
+    "humanoid_p_v0": dict(
+        qpos_names=["left_hip_pitch_joint", "right_hip_pitch_joint", "torso_joint", "left_hip_roll_joint", "right_hip_roll_joint",
+                    "left_shoulder_pitch_joint", "right_shoulder_pitch_joint", "left_hip_yaw_joint", "right_hip_yaw_joint",
+                    "left_shoulder_roll_joint", "right_shoulder_roll_joint", "left_knee_joint", "right_knee_joint",
+                    "left_shoulder_yaw_joint", "right_shoulder_yaw_joint", "left_ankle_pitch_joint", "right_ankle_pitch_joint",
+                    "left_elbow_pitch_joint", "right_elbow_pitch_joint", "left_ankle_roll_joint", "right_ankle_roll_joint",
+                    "left_elbow_yaw_joint", "right_elbow_yaw_joint"],
+        qvel_names=None,   # same list (:153)
+        geared=slice(0, 0), gear=1.0, info_state=[("pos", i) for i in range(23)],
+        init_height=1.105, init_noise="all", action_scale=None),
+}
+
+
+def hinge_addresses(xml_path: str) -> Dict[str, int]:
+    """joint name -> index k of the hinge in document order (qpos address 7 + k, dof address 6 + k)."""
+    import re
+    names = re.findall(r'<joint\s+name="([A-Za-z0-9_]+)"', open(xml_path).read())
+    assert names and "free" in names[0], "first joint of the cosim robots is the free joint"
+    return {n: k for k, n in enumerate(names[1:])}
+
+
+class RobotEnvOracle:
+    """What ``<Robot>._get_obs`` / ``_get_info`` read from ``self.data`` (noise excluded), given an ``Oracle``."""
+
+    def __init__(self, env_id: str, xml_path: str, hardware: dict):
+        self.r = ROBOT_ENV[env_id]
+        adr = hinge_addresses(xml_path)
+        qn = self.r["qpos_names"]
+        vn = self.r["qvel_names"] or qn
+        self.q_idx = np.array([7 + adr[n] for n in qn])
+        self.qd_idx = np.array([6 + adr[n] for n in vn])
+        g = self.r["gear"]
+        self.gear = float(hardware[g]) if isinstance(g, str) else float(g)
+        self.nhinge = len(adr)
+        self.noise_qadr = (np.arange(7, 7 + self.nhinge) if self.r["init_noise"] == "all"
+                           else np.array([7 + adr[n] for n in self.r["init_noise"]]))
+        sc = self.r["action_scale"]
+        self.action_scale = None if sc is None else np.array(sc(hardware), dtype=np.float64)
+
+    def obs(self, o, action, height_map=None) -> dict:
+        dof_pos, dof_vel = o.qpos[self.q_idx].copy(), o.qvel[self.qd_idx].copy()
+        s = self.r["geared"]
+        dof_pos[s] *= self.gear
+        dof_vel[s] *= self.gear
+        out = {"dof_pos": dof_pos, "dof_vel": dof_vel, "ang_vel": o.sensor_gyro.copy(), "lin_vel": o.sensor_vel.copy(),
+               "projected_gravity": projected_gravity(o.sensor_quat), "last_action": np.asarray(action, dtype=np.float64)}
+        if height_map is not None:
+            out["height_map"] = height_map
+        return out
+
+    def info(self, o, action, prev_action, torque) -> dict:
+        dof_pos, dof_vel = o.qpos[self.q_idx], o.qvel[self.qd_idx]
+        a, p = np.asarray(action, dtype=np.float64), np.asarray(prev_action, dtype=np.float64)
+        return {"action_diff_RMSE": float(np.sqrt(np.mean((a - p) ** 2))), "torque": np.asarray(torque, dtype=np.float64),
+                "lin_vel_x": float(o.sensor_vel[0]), "lin_vel_y": float(o.sensor_vel[1]), "ang_vel_yaw": float(o.sensor_gyro[2]),
+                "state": np.array([dof_pos[i] if k == "pos" else dof_vel[i] for k, i in self.r["info_state"]])}

@@ -64,3 +64,30 @@ def test_metrics_all_reduce_world_size_2():
     x = np.arange(10.0)
     assert out["a"]["count"] == 30 and out["a"]["mean"] == pytest.approx(x.mean()) and out["a"]["std"] == pytest.approx(x.std())
     assert out["b"]["mean"] == pytest.approx(-2 * x.mean()) and out["b"]["std"] == pytest.approx(2 * x.std())
+
+
+def test_bench_launcher_starts_its_own_ranks():
+    """`python bench.py --gpus 2` without a torchrun environment: the parent spawns the two ranks (torch.distributed.run) before
+    touching any GPU, rank 0 prints the one JSON line (skeleton only: --selftest-launch does no GPU work)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--selftest-launch"], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [json.loads(x) for x in p.stdout.splitlines() if x.startswith("{")]
+    assert len(lines) == 1 and lines[0]["n_gpus"] == 2 and lines[0]["max_rank"] == 1.0
+    assert lines[0]["count"] == 8 and lines[0]["mean"] == pytest.approx(1.5)
+
+
+def test_bench_launcher_command_and_rank_mismatch():
+    import importlib.util
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(root, "bench.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    cmd = b.relaunch_command(["--gpus", "4", "--steps", "7"], 4, 12345)
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node=4" in cmd and cmd[-4:] == ["--gpus", "4", "--steps", "7"]
+    assert "127.0.0.1" in cmd and "12345" in cmd and cmd[cmd.index("12345") + 1].endswith("bench.py")

@@ -29,6 +29,18 @@ def test_philox_known_answer_vectors():
     assert u.min() > 0 and u.max() < 1 and abs(u.mean() - 0.5) < 0.05
 
 
+def test_fleets_of_two_seeds_are_not_permutations_of_each_other():
+    # seed and env id sit in separate Philox words: (seed 0, env 1) and (seed 1, env 0) must not share a stream, and the
+    # fleet drawn under seed 1235 must not be the fleet of seed 1234 with its envs shuffled
+    assert crng.uniform(0, np.array([1]), 0, 0, 0)[0] != crng.uniform(1, np.array([0]), 0, 0, 0)[0]
+    g = np.arange(4096)
+    a = np.sort(crng.uniform(1234, g, 5, crng.PURPOSE_MASS, 2))
+    b = np.sort(crng.uniform(1235, g, 5, crng.PURPOSE_MASS, 2))
+    assert (a == b).mean() < 0.01
+    # distinct (purpose, index) pairs are distinct streams as well
+    assert crng.uniform(3, g, 1, 1, 2)[7] != crng.uniform(3, g, 1, 2, 1)[7]
+
+
 def test_config_matches_gui_defaults():
     cfg = make_config("flamingo_light_v1")
     assert cfg["random"] == dict(precision="medium", sensor_noise="low", init_noise=0.05, sliding_friction=0.8,
