@@ -31,7 +31,7 @@
 #define MINIMP 0.0001
 #define MAXIMP 0.9999
 #define MINMU 1e-5
-#define MAXCON 96
+#define MAXCON 1280
 #define MAXEFC (6 * CS_MAXEQ / 2 + 3 * CS_MAXDOF + 4 * MAXCON)
 #define NV CS_MAXDOF
 

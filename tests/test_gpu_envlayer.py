@@ -48,13 +48,15 @@ def test_randomised_masses_loads_and_gains_match_per_env_oracles():
     m0 = np.array(get_field(b, "body_mass")[:b.nbody])
     base = cm.body_names.index("base_link")
     # the draws are what XMLManager's are: listed bodies within +-5 %, the base additionally + load, the others nominal
-    rel = env.body_mass / m0[None] - 1.0
+    rel = env.body_mass[:, 1:] / m0[None, 1:] - 1.0                # (body 0 is the massless world)
     listed = [cm.body_names.index(x) for x in ("base_link", "left_shoulder_link", "right_shoulder_link", "left_wheel_link", "right_wheel_link")]
     others = [i for i in range(1, b.nbody) if i not in listed]
     assert np.abs(env.body_mass[:, others] - m0[None, others]).max() == 0.0
     assert np.all(np.abs(env.body_mass[:, base] - 1.0 - m0[base]) <= 0.05 * m0[base] + 1e-12)
-    assert np.abs(rel[:, listed[1:]]).max() <= 0.05 + 1e-12 and rel[:, listed[1:]].std() > 0.02
-    assert np.abs(env.kp / env.kp.mean(0) - 1).max() <= 0.11 and (env.kd.std(0) > 0).all()
+    lr = rel[:, [i - 1 for i in listed[1:]]]
+    assert np.abs(lr).max() <= 0.05 + 1e-12 and lr.std() > 0.02
+    kp0, kd0 = np.array(get_field(b, "ctl_kp")[:b.nu]), np.array(get_field(b, "ctl_kd")[:b.nu])
+    assert np.abs(env.kp - kp0).max() <= 0.1 * kp0.max() + 1e-9 and (np.abs(env.kd / kd0 - 1).max(axis=0) > 0.05).all()
 
     q0 = np.array(get_field(b, "init_qpos")[:b.nq])
     rng = np.random.default_rng(5)
@@ -70,7 +72,7 @@ def test_randomised_masses_loads_and_gains_match_per_env_oracles():
         R["tq"].append(o.control_step(a))
         R["qpos1"].append(o.qpos.copy()); R["qvel1"].append(o.qvel.copy()); R["ncon"].append(o.ncon)
     R = {k: np.array(v) for k, v in R.items()}
-    assert R["ncon"].min() >= 2                                       # every env stands on something: contact rows are live
+    assert R["ncon"].min() >= 1 and np.median(R["ncon"]) >= 4         # every env stands on something: contact rows are live
 
     def replay(e_):
         e_.reset()
