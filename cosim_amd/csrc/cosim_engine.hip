@@ -59,11 +59,12 @@ struct cosim_engine {
   void (*launch_prof2)(cosim_engine*, const KArgs&, int grid, hipStream_t) = nullptr;
   int epw = 1;   // environments per wave of the reset / step launches
   int lds_bytes = 0;
+  int contact_slots = 0;   // ground-contact capacity of the selected kernel
 };
 
-template <int NV, int NB, int RPL, bool HF, int GTM, bool SC>
+template <int NV, int NB, int RPL, bool HF, int GTM, bool SC, int MCT>
 static void launch_t(cosim_engine* e, const KArgs& a, int grid, hipStream_t s) {
-  hipLaunchKernelGGL((env_kernel<NV, NB, RPL, HF, GTM, SC>), dim3(grid), dim3(64), 0, s, a);
+  hipLaunchKernelGGL((env_kernel<NV, NB, RPL, HF, GTM, SC, false, 1, MCT>), dim3(grid), dim3(64), 0, s, a);
 }
 template <int NV, int NB, int RPL, int GTM>
 static void launch_prof_t(cosim_engine* e, const KArgs& a, int grid, hipStream_t s) {
@@ -77,10 +78,12 @@ template <int NV, int NB, int GTM>
 static void launch_prof2_t(cosim_engine* e, const KArgs& a, int grid, hipStream_t s) {
   hipLaunchKernelGGL((env_kernel<NV, NB, 2, false, GTM, false, true, 2>), dim3((grid + 1) / 2), dim3(64), 0, s, a);
 }
-template <int NV, int NB, int RPL, int GTM, bool SC>
+// MCT_FLAT / MCT_HF: ground-contact slots of the contact-twist kernels on a plane / on a heightfield (0: dense contact rows)
+template <int NV, int NB, int RPL, int GTM, bool SC, int MCT_FLAT, int MCT_HF>
 static void select_t(cosim_engine* e, bool hf) {
-  e->launch = hf ? launch_t<NV, NB, RPL, true, GTM, SC> : launch_t<NV, NB, RPL, false, GTM, SC>;
-  e->lds_bytes = (hf || SC) ? (int)sizeof(EnvLds<NV, NB, RPL, true>) : (int)sizeof(EnvLds<NV, NB, RPL, false>);
+  e->launch = hf ? launch_t<NV, NB, RPL, true, GTM, SC, MCT_HF> : launch_t<NV, NB, RPL, false, GTM, SC, MCT_FLAT>;
+  e->lds_bytes = hf ? (int)sizeof(EnvLds<NV, NB, RPL, true, 64, MCT_HF>) : (int)sizeof(EnvLds<NV, NB, RPL, SC, 64, MCT_FLAT>);
+  e->contact_slots = hf ? EnvLds<NV, NB, RPL, true, 64, MCT_HF>::MC : EnvLds<NV, NB, RPL, SC, 64, MCT_FLAT>::MC;
 }
 
 static int round_up(int x, int m) { return (x + m - 1) / m * m; }
@@ -400,10 +403,10 @@ int cosim_create(const cosim_model_t* model, const float* hull_vert, const int* 
     }
   }
   constexpr int G_LIGHT = GT_SPHERE | GT_CYLINDER | GT_MESH, G_MESH = GT_MESH, G_HUM = GT_BOX | GT_CYLINDER | GT_MESH;
-  if (nv == 18 && nb <= 14 && (gtm & ~G_LIGHT) == 0) { select_t<18, 14, 1, G_LIGHT, false>(e, hf); if (!hf) { e->launch_prof = launch_prof_t<18, 14, 1, G_LIGHT>; e->launch2 = launch2_t<18, 14, G_LIGHT>; e->launch_prof2 = launch_prof2_t<18, 14, G_LIGHT>; } }   // flamingo_light_v1
-  else if (nv == 14 && nb <= 10 && (gtm & ~G_MESH) == 0) select_t<14, 10, 2, G_MESH, true>(e, hf);   // flamingo_p_v3
-  else if (nv == 22 && nb <= 18 && (gtm & ~G_MESH) == 0) select_t<22, 18, 2, G_MESH, true>(e, hf);   // w4_p_v2
-  else if (nv == 29 && nb <= 26 && (gtm & ~G_HUM) == 0) select_t<29, 26, 2, G_HUM, true>(e, hf);     // humanoid_p_v0
+  if (nv == 18 && nb <= 14 && (gtm & ~G_LIGHT) == 0) { select_t<18, 14, 1, G_LIGHT, false, 0, 128>(e, hf); if (!hf) { e->launch_prof = launch_prof_t<18, 14, 1, G_LIGHT>; e->launch2 = launch2_t<18, 14, G_LIGHT>; e->launch_prof2 = launch_prof2_t<18, 14, G_LIGHT>; } }   // flamingo_light_v1
+  else if (nv == 14 && nb <= 10 && (gtm & ~G_MESH) == 0) select_t<14, 10, 2, G_MESH, true, 64, 64>(e, hf);   // flamingo_p_v3
+  else if (nv == 22 && nb <= 18 && (gtm & ~G_MESH) == 0) select_t<22, 18, 2, G_MESH, true, 128, 128>(e, hf);   // w4_p_v2
+  else if (nv == 29 && nb <= 26 && (gtm & ~G_HUM) == 0) select_t<29, 26, 2, G_HUM, true, 128, 256>(e, hf);     // humanoid_p_v0
   else { delete e; return fail(COSIM_EINVAL, "cosim_create: no kernel instantiation for this (nv, nbody); add one in cosim_engine.hip"); }
   HIP_TRY(hipMalloc(&e->d_model, sizeof(DevModel)));
   HIP_TRY(hipMalloc(&e->d_obs, sizeof(DevObs)));
@@ -480,6 +483,7 @@ int cosim_query(const cosim_engine_t* e, const char* name) {
   if (n == "state_stride") return e->lay.s_stride;
   if (n == "param_stride") return e->lay.p_stride;
   if (n == "lds_bytes") return e->lds_bytes;
+  if (n == "contact_slots") return e->contact_slots;
   if (n == "stacked_dim") return e->ho.stacked_dim;
   if (n == "frame_dim") return e->ho.frame_dim;
   return fail(COSIM_EINVAL, "cosim_query: unknown name " + n);

@@ -198,12 +198,35 @@ __device__ __forceinline__ unsigned philox_first(unsigned k0, unsigned k1, unsig
 __device__ __forceinline__ float u01(unsigned x) { return (float)(x >> 8) * (1.0f / 16777216.0f) + (0.5f / 16777216.0f); }  // (0,1)
 
 // ------------------------------------------------------------------------------------------------ LDS per env
-template <int NV, int NB, int RPL, bool NRM, int LW = 64>   // NRM: contact normals are stored (heightfield ground or robot-robot pairs)
-struct EnvLds {
+// MCT > 0 ("contact-twist" mode, CT): ground contacts do not become dense Jacobian rows.  A ground contact touches one body, so
+// each of its four pyramid rows is w_e . twist_b(v) with a 6-vector w_e = [off x d_e; d_e] (d_e = n +- mu t, off = point - com) and
+// the body's twist  twist_b(v) = sum_{j in chain(b)} cdof_j v_j:  J v is three dot products per contact, J^T f a per-body wrench
+// pushed through the tree, and J^T D J a per-body 6 x 6 matrix pushed through the tree exactly like the composite inertia of
+// mj_crb.  The solver's cost per Newton iteration then hardly depends on the number of contact rows, and the contact capacity
+// (MCT slots, LW per pass) is a loop bound instead of a register count: humanoid_p_v0 on the 1 cm stairs terrains emits up to 50
+// contacts per geom (mjc_ConvexHField), hundreds per env.  Robot-robot contacts (two bodies) keep dense rows (MCP slots).
+// CT: robot-robot contacts in slots of their own; per ground contact the regulariser D, the four rows' J a - aref and J s;
+// per body: twist of the vector in flight, contact wrench, 6 x 6 contact "inertia" (lower triangle, 21 entries).  Empty otherwise
+// (the one-env-per-wave kernel of flamingo_light_v1 must stay within 160 KiB / 16 = 10240 B of LDS).
+template <bool CT, int NB, int MC, int MCP>
+struct CtLds {
+  float ppos[MCP][3], pnrm[MCP][3], pdist[MCP];
+  int pgeom[MCP];
+  float cD[MC], cJar[MC][4], cJv[MC][4];
+  float tw[NB][6], bw[NB][6], bW[NB][21];
+  unsigned cbmask;   // bodies that carry a ground contact
+};
+template <int NB, int MC, int MCP>
+struct CtLds<false, NB, MC, MCP> {};
+template <int NV, int NB, int RPL, bool NRM, int LW = 64, int MCT = 0>   // NRM: contact normals are stored (heightfield ground or robot-robot pairs)
+struct EnvLds : CtLds<(MCT > 0), NB, (MCT > 0 ? MCT : 1), 12> {
+  static constexpr bool CT = MCT > 0;
   static constexpr int LD = NV | 1;   // odd leading dimension: conflict-free column access
   static constexpr int ROWS = LW * RPL;            // constraint rows per env: RPL rows per lane, LW lanes per env
-  static constexpr int MC = ROWS <= 64 ? 12 : 16;  // contact slots (4 pyramid rows each)
-  static constexpr int NGEN = 3 * MAXEQ / 2 + 4 * MC;  // dense rows: 2 connect equalities (6 rows) + contacts
+  static constexpr int MC = CT ? MCT : (ROWS <= 64 ? 12 : 16);  // contact slots (4 pyramid rows each); CT: ground contacts only
+  static constexpr int MCP = CT ? 12 : 1;          // CT: robot-robot contact slots (dense rows)
+  static constexpr int CPL = (MC + LW - 1) / LW;   // CT: contacts per lane = passes over the contact list
+  static constexpr int NGEN = 3 * MAXEQ / 2 + 4 * (CT ? MCP : MC);  // dense rows: 2 connect equalities (6 rows) + contacts
   static constexpr int NLIM = ROWS / 8;
   static constexpr int NUMAX = NV - 6;   // actuators: at most one per hinge dof (the free joint's six dofs carry none)
   float qpos[CS_MAXQ], qvel[NV], qacc[NV], qact[NV], qsm[NV], qcon[NV], sr[NV], dofD[NV];
@@ -229,6 +252,15 @@ struct EnvLds {
   float com[3];
   int ncon_ctr;
 };
+
+// contact i of the list a dense row / the debug dump / the termination test walks: in CT mode ground contacts come first, then the
+// robot-robot contacts of the p* slots (index i - ncon); otherwise one list
+template <bool CT, class LDS> __device__ __forceinline__ int con_geom(LDS& S, bool gnd, int c, int cp) { if constexpr (CT) return gnd ? S.cgeom[gnd ? c : 0] : S.pgeom[gnd ? 0 : cp]; else return S.cgeom[c]; }
+template <bool CT, class LDS> __device__ __forceinline__ float con_dist(LDS& S, bool gnd, int c, int cp) { if constexpr (CT) return gnd ? S.cdist[gnd ? c : 0] : S.pdist[gnd ? 0 : cp]; else return S.cdist[c]; }
+template <bool CT, class LDS> __device__ __forceinline__ const float* con_pos(LDS& S, bool gnd, int c, int cp) { if constexpr (CT) return gnd ? S.cpos[gnd ? c : 0] : S.ppos[gnd ? 0 : cp]; else return S.cpos[c]; }
+template <bool CT, bool NRM, class LDS> __device__ __forceinline__ const float* con_nrm(LDS& S, bool gnd, int c, int cp) {   // NRM false: not stored (+z), do not read
+  if constexpr (CT) return gnd ? S.cnrm[(NRM && gnd) ? c : 0] : S.pnrm[gnd ? 0 : cp]; else return S.cnrm[NRM ? c : 0];
+}
 
 // ------------------------------------------------------------------------------------------------ Cholesky
 // Lane i < NV holds row i of a symmetric positive definite matrix in a[0..NV).  Right-looking factorisation with the
@@ -423,12 +455,15 @@ __device__ __forceinline__ float impedance(const float* solimp, float pos, float
 // ------------------------------------------------------------------------------------------------ the kernel
 // HF: heightfield ground; SC: robot-robot (self) collision pairs; PROF: diagnostic build with s_memtime phase stamps;
 // EPW: environments per wave (1: lane l of 64 plays object l; 2: two groups of 32 lanes, RPL rows per lane of the group)
-template <int NV, int NB, int RPL, bool HF, int GTM, bool SC, bool PROF = false, int EPW = 1>
-__global__ __launch_bounds__(64, (RPL == 1 && EPW == 1 && !HF) ? 4 : ((EPW == 1 && NV < 18) ? 4 : 2))   /* flamingo_p_v3: LDS allows 16 waves/CU; 2 / 3 / 4 per SIMD measured 6.83 / 7.06 / 7.31 M env-steps/s */ void env_kernel(KArgs A) {
+template <int NV, int NB, int RPL, bool HF, int GTM, bool SC, bool PROF = false, int EPW = 1, int MCT = 0>
+__global__ __launch_bounds__(64, (RPL == 1 && EPW == 1 && !HF) ? 4 : ((EPW == 1 && NV < 18 && MCT <= 64) ? 4 : 2))   /* flamingo_p_v3: LDS allows 16 waves/CU; 2 / 3 / 4 per SIMD measured 6.83 / 7.06 / 7.31 M env-steps/s */ void env_kernel(KArgs A) {
   static_assert(EPW == 1 || (EPW == 2 && !HF && !SC && NV <= 32 && NB <= 32), "two environments per wave: flat ground, no pairs");
+  static_assert(MCT == 0 || EPW == 1, "contact-twist mode: one environment per wave");
   constexpr bool NRM = HF || SC;
   constexpr int LW = 64 / EPW;
-  using L = EnvLds<NV, NB, RPL, NRM, LW>;
+  constexpr bool CT = MCT > 0;
+  using L = EnvLds<NV, NB, RPL, NRM, LW, MCT>;
+  constexpr int CPL = L::CPL;
   constexpr int MAXROWS = L::ROWS;
   constexpr int TRI = NV * (NV + 1) / 2;
   constexpr int MC = L::MC;
@@ -825,6 +860,7 @@ __global__ __launch_bounds__(64, (RPL == 1 && EPW == 1 && !HF) ? 4 : ((EPW == 1 
       STAMP(4);   // comVel + rne + sensors
       // =========================================================== collision: ground (plane or heightfield) vs robot geoms
       int ncon = 0;
+      int npc = 0;   // CT: robot-robot contacts (slots of their own, dense rows); otherwise they follow the ground contacts in ncon
       {
         const LaneRec& R = dm.rec[ln];
         constexpr bool is_plane = !HF;
@@ -1033,6 +1069,17 @@ __global__ __launch_bounds__(64, (RPL == 1 && EPW == 1 && !HF) ? 4 : ((EPW == 1 
             qmul(o.q, bq, G.g_quat);
           }
         };
+        auto pair_put = [&](int slot, float dist, int code, const float* pp, const float* nn) {
+          if constexpr (CT) {
+            if (slot < L::MCP) {
+              S.pdist[slot] = dist; S.pgeom[slot] = code;
+              for (int k = 0; k < 3; k++) { S.ppos[slot][k] = pp[k]; S.pnrm[slot][k] = nn[k]; }
+            }
+          } else if (slot < MC) {
+            S.cdist[slot] = dist; S.cgeom[slot] = code;
+            for (int k = 0; k < 3; k++) { S.cpos[slot][k] = pp[k]; S.cnrm[NRM ? slot : 0][k] = nn[k]; }
+          }
+        };
         const int npair = dm.npair;
         for (int p0 = 0; p0 < npair; p0 += 64) {
           const int p = p0 + ln;
@@ -1088,13 +1135,9 @@ __global__ __launch_bounds__(64, (RPL == 1 && EPW == 1 && !HF) ? 4 : ((EPW == 1 
           }
           {
             const unsigned long long hm = __ballot(hit);
-            const int slot = ncon + __popcll(hm & lanemask_lt(ln));
-            if (hit && slot < MC) {
-              S.cdist[slot] = -depth;
-              S.cgeom[slot] = g2 | ((g1 + 1) << 8);
-              for (int k = 0; k < 3; k++) { S.cpos[slot][k] = cp[k]; S.cnrm[NRM ? slot : 0][k] = cn[k]; }
-            }
-            ncon += __popcll(hm);
+            const int slot = (CT ? npc : ncon) + __popcll(hm & lanemask_lt(ln));
+            if (hit) pair_put(slot, -depth, g2 | ((g1 + 1) << 8), cp, cn);
+            if constexpr (CT) npc += __popcll(hm); else ncon += __popcll(hm);
           }
           if constexpr ((GTM & GT_MESH) != 0) {
             unsigned long long mm = __ballot(mesh);
@@ -1109,12 +1152,8 @@ __global__ __launch_bounds__(64, (RPL == 1 && EPW == 1 && !HF) ? 4 : ((EPW == 1 
               float dep2 = 0.f, n2[3] = {0.f, 0.f, 1.f}, c2[3] = {0.f, 0.f, 0.f};
               const bool hit2 = mpr_penetration(sup, o1.center, o2.center, dep2, n2, c2) && (n2[0] != 0.f || n2[1] != 0.f || n2[2] != 0.f);
               if (hit2) {
-                if (ln == 0 && ncon < MC) {
-                  S.cdist[ncon] = -dep2;
-                  S.cgeom[ncon] = h2 | ((h1 + 1) << 8);
-                  for (int k = 0; k < 3; k++) { S.cpos[ncon][k] = c2[k]; S.cnrm[NRM ? ncon : 0][k] = n2[k]; }
-                }
-                ncon++;
+                if (ln == 0) pair_put(CT ? npc : ncon, -dep2, h2 | ((h1 + 1) << 8), c2, n2);
+                if constexpr (CT) npc++; else ncon++;
               }
             }
           }
@@ -1147,17 +1186,25 @@ __global__ __launch_bounds__(64, (RPL == 1 && EPW == 1 && !HF) ? 4 : ((EPW == 1 
         // capacity (MuJoCo's arena holds every contact; here the slots are sized per kernel variant): whatever does not fit is
         // left out in detection order AND counted -- meta[8] / solver_stats()["dropped_contacts"] is non-zero whenever an env
         // was stepped with a truncated constraint set
-        const int ncon_all = ncon;
+        const int ncon_all = ncon + npc;
         int room = (MAXROWS - ne - nf - nl) / 4;
         if (room < 0) room = 0;
-        if (ncon > room) ncon = room;
-        if (ncon > MC) ncon = MC;
-        if (ne + 4 * ncon > NGENMAX) ncon = (NGENMAX - ne) / 4;
-        st_dropcon += ncon_all - ncon;
+        if constexpr (CT) {   // ground contacts: slots only; robot-robot contacts: slots and dense rows
+          if (ncon > MC) ncon = MC;
+          if (npc > room) npc = room;
+          if (npc > L::MCP) npc = L::MCP;
+          if (ne + 4 * npc > NGENMAX) npc = (NGENMAX - ne) / 4;
+        } else {
+          if (ncon > room) ncon = room;
+          if (ncon > MC) ncon = MC;
+          if (ne + 4 * ncon > NGENMAX) ncon = (NGENMAX - ne) / 4;
+        }
+        st_dropcon += ncon_all - ncon - npc;
         st_maxcon = max(st_maxcon, ncon_all);
       }
-      const int ngen = ne + 4 * ncon;       // general rows (dense J): equality + contact
-      const int nefc = ngen + nf + nl;      // then unit rows: frictionloss, limits
+      const int ndc = CT ? npc : ncon;      // contacts with dense rows
+      const int ngen = ne + 4 * ndc;        // general rows (dense J): equality + contact
+      const int nefc = ngen + nf + nl + (CT ? 4 * ncon : 0);   // then unit rows (frictionloss, limits); CT: + the ground contacts' rows
       WSYNC();
 
       // per-lane row state: row (ln + LW rr), rr < RPL
@@ -1199,19 +1246,21 @@ __global__ __launch_bounds__(64, (RPL == 1 && EPW == 1 && !HF) ? 4 : ((EPW == 1 
           } else {
             rtype[rr] = RT_CONTACT;
             const int c = (row - ne) >> 2, edge = (row - ne) & 3;
-            const int gg = S.cgeom[c], g = gg & 0xff, g1 = (gg >> 8) - 1;   // g1 < 0: geom1 is the ground
+            const int gg = con_geom<CT>(S, !CT, c, c), g = gg & 0xff, g1 = (gg >> 8) - 1;   // g1 < 0: geom1 is the ground (CT: dense rows are robot-robot contacts)
             const LaneRec& G = dm.rec[g];
             const int b = G.g_body, b1 = (SC && g1 >= 0) ? dm.rec[g1].g_body : 0;
             const float mu = (SC && g1 >= 0) ? fmaxf(MINMU, fmaxf(A.gext[g].w, A.gext[g1].w)) : S.p_gmu[g];
-            float nrm[3] = {NRM ? S.cnrm[NRM ? c : 0][0] : 0.f, NRM ? S.cnrm[NRM ? c : 0][1] : 0.f, NRM ? S.cnrm[NRM ? c : 0][2] : 1.f}, t1[3], t2[3];
+            const float* cn_ = con_nrm<CT, NRM>(S, !CT, c, c);
+            const float* cp_ = con_pos<CT>(S, !CT, c, c);
+            float nrm[3] = {NRM ? cn_[0] : 0.f, NRM ? cn_[1] : 0.f, NRM ? cn_[2] : 1.f}, t1[3], t2[3];
             make_frame(nrm, t1, t2);
             const float* tk = (edge >> 1) ? t2 : t1;
             const float sg = (edge & 1) ? -mu : mu;
-            for (int k = 0; k < 3; k++) { dir[k] = nrm[k] + sg * tk[k]; offA[k] = S.cpos[c][k] - com[k]; offB[k] = offA[k]; }
+            for (int k = 0; k < 3; k++) { dir[k] = nrm[k] + sg * tk[k]; offA[k] = cp_[k] - com[k]; offB[k] = offA[k]; }
             // mj_jacDifPair: jac(body2) - jac(body1) at one point; dofs common to both chains cancel
             const unsigned m2 = dm.rec[b].b_dofmask, m1 = (SC && g1 >= 0) ? dm.rec[b1].b_dofmask : 0u;
             maskA = m2 & ~m1; maskB = m1 & ~m2;
-            rpos = S.cdist[c];
+            rpos = con_dist<CT>(S, !CT, c, c);
             rmargin = G.g_incmargin;
             rmu = mu;
             rdiagA = (S.p_binvw[b] + ((SC && g1 >= 0) ? S.p_binvw[b1] : 0.f)) * (1.f + mu * mu);
@@ -1272,6 +1321,61 @@ __global__ __launch_bounds__(64, (RPL == 1 && EPW == 1 && !HF) ? 4 : ((EPW == 1 
         }
         if (rr == 0) rpos_dbg = rpos;
       }
+      // ---- CT: ground contacts in twist space
+      struct CGeo { float n[3], t1[3], t2[3], off[3], mu; int b, g; };
+      auto cgeo = [&](int c, CGeo& G) {   // frame, lever arm about the tree's CoM, friction and body of ground contact c
+        G.g = S.cgeom[c] & 0xff;
+        G.b = dm.rec[G.g].g_body;
+        G.mu = S.p_gmu[G.g];
+        for (int k = 0; k < 3; k++) { G.n[k] = NRM ? S.cnrm[NRM ? c : 0][k] : (k == 2 ? 1.f : 0.f); G.off[k] = S.cpos[c][k] - com[k]; }
+        make_frame(G.n, G.t1, G.t2);
+      };
+      auto point_proj = [&](const float* tw, const CGeo& G, float& pn, float& p1, float& p2) {   // (n, t1, t2) . (v + w x off)
+        float wxo[3];
+        cross(wxo, tw, G.off);
+        const float vp[3] = {tw[3] + wxo[0], tw[4] + wxo[1], tw[5] + wxo[2]};
+        pn = dot3(G.n, vp); p1 = dot3(G.t1, vp); p2 = dot3(G.t2, vp);
+      };
+      auto body_twists = [&](const float* v1, const float* v2, float (*o1)[6], float (*o2)[6]) {   // o1[b] = sum_j cdof_j v1_j over chain(b); o2[b] likewise for v2 (may be null)
+        if (ln > 0 && ln < nbody) {
+          float a[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, b2[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+          for (unsigned mk = dm.rec[ln].b_dofmask; mk; mk &= mk - 1) {
+            const int j = __builtin_ctz(mk);
+            const float x1 = v1[j], x2 = v2 != nullptr ? v2[j] : 0.f;
+#pragma unroll
+            for (int q = 0; q < 6; q++) { const float cq = S.cdof[j][q]; a[q] += cq * x1; b2[q] += cq * x2; }
+          }
+#pragma unroll
+          for (int q = 0; q < 6; q++) { o1[ln][q] = a[q]; if (v2 != nullptr) o2[ln][q] = b2[q]; }
+        }
+        WSYNC();
+      };
+      if constexpr (CT) {
+        if (ln == 0) S.cbmask = 0u;
+        body_twists(S.qvel, S.qacc, S.tw, S.bw);   // twists of the velocity and of the warm-start acceleration
+#pragma unroll
+        for (int cc = 0; cc < CPL; cc++) {
+          const int c = ln + LW * cc;
+          if (c < ncon) {
+            CGeo G;
+            cgeo(c, G);
+            const LaneRec& GR = dm.rec[G.g];
+            float vn, v1, v2, an, a1, a2;
+            point_proj(S.tw[G.b], G, vn, v1, v2);
+            point_proj(S.bw[G.b], G, an, a1, a2);
+            const float rpos = S.cdist[c], rmargin = GR.g_incmargin;
+            const float imp = impedance(GR.g_solimp, rpos, rmargin), K = GR.g_solref[0], B = GR.g_solref[1];
+            float rR = fmaxf(MINVAL, (1.f - imp) * S.p_binvw[G.b] * (1.f + G.mu * G.mu) / imp);
+            const float mur = G.mu * rsqrtf(fmaxf(MINVAL, dm.impratio));
+            rR = 2.f * mur * mur * rR;
+            S.cD[c] = 1.f / rR;
+            // row e = n +- mu t_k:  J a - aref = (a_n +- mu a_k) + B (v_n +- mu v_k) + K imp (r - margin)
+            const float base = an + B * vn + K * imp * (rpos - rmargin), x1 = G.mu * (a1 + B * v1), x2 = G.mu * (a2 + B * v2);
+            S.cJar[c][0] = base + x1; S.cJar[c][1] = base - x1; S.cJar[c][2] = base + x2; S.cJar[c][3] = base - x2;
+            atomicOr(&S.cbmask, 1u << G.b);
+          }
+        }
+      }
       WSYNC();
 
       STAMP(6);   // constraint rows
@@ -1309,10 +1413,21 @@ __global__ __launch_bounds__(64, (RPL == 1 && EPW == 1 && !HF) ? 4 : ((EPW == 1 
       float dact_cur[RPL], dact_fac[RPL];  // this row's active D now / when H was last factorised
 #pragma unroll
       for (int rr = 0; rr < RPL; rr++) { dact_cur[rr] = 0.f; dact_fac[rr] = -1.f; }
+      int cact_cur[CPL], cact_fac[CPL];    // CT: active edges (4 bits) of this lane's ground contacts now / at the last factorisation
+#pragma unroll
+      for (int cc = 0; cc < CPL; cc++) { cact_cur[cc] = 0; cact_fac[cc] = -1; }
+      unsigned cbmask = 0u;
+      if constexpr (CT) cbmask = S.cbmask;
       auto update_constraint = [&]() {
         // mj_constraintUpdate: force, active set, cost
         float csum = 0.f;
         if (ln < NV) { S.dofD[ln] = 0.f; S.qcon[ln] = 0.f; }
+        if constexpr (CT) {
+          if (ln < nbody) {
+#pragma unroll
+            for (int q = 0; q < 6; q++) S.bw[ln][q] = 0.f;
+          }
+        }
 #pragma unroll
         for (int rr = 0; rr < RPL; rr++) {
           // branch-free over the row kinds (lanes of one wave hold different kinds): rows of kind NONE carry D = 0, f = 0
@@ -1334,11 +1449,52 @@ __global__ __launch_bounds__(64, (RPL == 1 && EPW == 1 && !HF) ? 4 : ((EPW == 1 
             atomicAdd(&S.dofD[rdof[rr]], dact_cur[rr]);
             atomicAdd(&S.qcon[rdof[rr]], rsign[rr] * S.w.r.rowf[ln + LW * rr]);
           }
+        if constexpr (CT) {
+          // ground contacts: one-sided quadratic rows (active while J a - aref < 0); their forces as one wrench per body
+#pragma unroll
+          for (int cc = 0; cc < CPL; cc++) {
+            const int c = ln + LW * cc;
+            int bits = 0;
+            if (c < ncon) {
+              const float D = S.cD[c];
+              float f[4];
+#pragma unroll
+              for (int e = 0; e < 4; e++) {
+                const float x = S.cJar[c][e];
+                const bool on = x < 0.f;
+                f[e] = on ? -D * x : 0.f;
+                csum += on ? 0.5f * D * x * x : 0.f;
+                bits |= on ? (1 << e) : 0;
+              }
+              if (bits) {
+                CGeo G;
+                cgeo(c, G);
+                const float fn = f[0] + f[1] + f[2] + f[3], f1 = G.mu * (f[0] - f[1]), f2 = G.mu * (f[2] - f[3]);
+                float F[3], T[3];
+                for (int k = 0; k < 3; k++) F[k] = G.n[k] * fn + G.t1[k] * f1 + G.t2[k] * f2;
+                cross(T, G.off, F);
+                for (int k = 0; k < 3; k++) { atomicAdd(&S.bw[G.b][k], T[k]); atomicAdd(&S.bw[G.b][3 + k], F[k]); }
+              }
+            }
+            cact_cur[cc] = bits;
+          }
+        }
         WSYNC();
         float qc = 0.f;
         if (ln < NV) {
           qc = S.qcon[ln];
           for (int r = 0; r < ngen; r++) qc += S.J[r][ln] * S.w.r.rowf[r];
+          if constexpr (CT) {
+            // J^T f of the ground contacts: cdof . (sum of the wrenches on the bodies this dof moves)
+            float W[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            for (unsigned mk = dm.rec[dm.rec[ln].d_body].b_subtree & cbmask; mk; mk &= mk - 1) {
+              const int b = __builtin_ctz(mk);
+#pragma unroll
+              for (int q = 0; q < 6; q++) W[q] += S.bw[b][q];
+            }
+#pragma unroll
+            for (int q = 0; q < 6; q++) qc += S.cdof[ln][q] * W[q];
+          }
           S.qcon[ln] = qc;
         }
         gauss = grp_sum<LW>(ln < NV ? (0.5f * Ma - qsm_l) * qacc_l : 0.f);
@@ -1354,6 +1510,8 @@ __global__ __launch_bounds__(64, (RPL == 1 && EPW == 1 && !HF) ? 4 : ((EPW == 1 
         bool changed = false;
 #pragma unroll
         for (int rr = 0; rr < RPL; rr++) changed = changed || (dact_cur[rr] != dact_fac[rr]);
+#pragma unroll
+        for (int cc = 0; cc < CPL; cc++) changed = changed || (CT && cact_cur[cc] != cact_fac[cc]);
         changed = changed && act;
         unsigned long long q0_ = 0;
         if (PROF) { __builtin_amdgcn_s_waitcnt(0); q0_ = __builtin_amdgcn_s_memtime(); }
@@ -1361,6 +1519,8 @@ __global__ __launch_bounds__(64, (RPL == 1 && EPW == 1 && !HF) ? 4 : ((EPW == 1 
         if (__ballot(changed) != 0ull) {
 #pragma unroll
           for (int rr = 0; rr < RPL; rr++) dact_fac[rr] = dact_cur[rr];
+#pragma unroll
+          for (int cc = 0; cc < CPL; cc++) cact_fac[cc] = cact_cur[cc];
           static_assert(NV <= 32, "one 32x32 MFMA tile");
           if constexpr (EPW == 1) {
              // H = M + (D J)^T J on the matrix pipe: v_mfma_f32_32x32x2_f32, two constraint rows per instruction
@@ -1419,6 +1579,68 @@ __global__ __launch_bounds__(64, (RPL == 1 && EPW == 1 && !HF) ? 4 : ((EPW == 1 
             // unit rows (frictionloss, limits) only touch the diagonal: added in LDS (one dynamic access) so that the row
             // comes out as plain reads; lanes past NV factor a copy of row 0, which nobody reads
             if (ln < NV) S.u.H[ln][ln] += S.dofD[ln];
+            if constexpr (CT) {
+              // J^T D J of the active ground-contact rows: per body the 6 x 6 matrix sum_e D w_e w_e^T (lower triangle), then through
+              // the tree like a composite inertia: H[i][j] += cdof_i^T (sum over the subtree of i) cdof_j for j an ancestor of i
+              for (int i = ln; i < nbody * 21; i += LW) (&S.bW[0][0])[i] = 0.f;
+              WSYNC();
+#pragma unroll
+              for (int cc = 0; cc < CPL; cc++) {
+                const int c = ln + LW * cc, bits = cact_cur[cc];
+                if (c < ncon && bits) {
+                  CGeo G;
+                  cgeo(c, G);
+                  const float D = S.cD[c];
+                  float acc[21];
+#pragma unroll
+                  for (int i = 0; i < 21; i++) acc[i] = 0.f;
+#pragma unroll
+                  for (int e = 0; e < 4; e++) {
+                    const float De = ((bits >> e) & 1) ? D : 0.f, sg = (e & 1) ? -G.mu : G.mu;
+                    const float* tk = (e >> 1) ? G.t2 : G.t1;
+                    float w[6];
+                    for (int k = 0; k < 3; k++) w[3 + k] = G.n[k] + sg * tk[k];
+                    cross(w, G.off, w + 3);
+#pragma unroll
+                    for (int i = 0, x = 0; i < 6; i++)
+#pragma unroll
+                      for (int j = 0; j <= i; j++, x++) acc[x] += De * w[i] * w[j];
+                  }
+#pragma unroll
+                  for (int i = 0; i < 21; i++) atomicAdd(&S.bW[G.b][i], acc[i]);
+                }
+              }
+              WSYNC();
+              if (ln < NV) {
+                const LaneRec& R = dm.rec[ln];
+                const unsigned sub = dm.rec[R.d_body].b_subtree & cbmask;
+                if (sub) {
+                  float Wc[21];
+#pragma unroll
+                  for (int i = 0; i < 21; i++) Wc[i] = 0.f;
+                  for (unsigned mk = sub; mk; mk &= mk - 1) {
+                    const int b = __builtin_ctz(mk);
+#pragma unroll
+                    for (int i = 0; i < 21; i++) Wc[i] += S.bW[b][i];
+                  }
+                  float cdi[6], y[6];
+#pragma unroll
+                  for (int q = 0; q < 6; q++) { cdi[q] = S.cdof[ln][q]; y[q] = 0.f; }
+#pragma unroll
+                  for (int i = 0, x = 0; i < 6; i++)
+#pragma unroll
+                    for (int j = 0; j <= i; j++, x++) { y[i] += Wc[x] * cdi[j]; if (j != i) y[j] += Wc[x] * cdi[i]; }
+                  for (unsigned mk = R.d_ancmask; mk; mk &= mk - 1) {
+                    const int j = __builtin_ctz(mk);
+                    float v = 0.f;
+#pragma unroll
+                    for (int q = 0; q < 6; q++) v += S.cdof[j][q] * y[q];
+                    S.u.H[ln][j] += v;
+                    if (j != ln) S.u.H[j][ln] += v;
+                  }
+                }
+              }
+            }
             WSYNC();
             const float* Hr = S.u.H[ln < NV ? ln : 0];
 #pragma unroll
@@ -1441,15 +1663,28 @@ __global__ __launch_bounds__(64, (RPL == 1 && EPW == 1 && !HF) ? 4 : ((EPW == 1 
       if (A.mode == MODE_DEBUG && A.dbg != nullptr) {
         // dump position/velocity-stage intermediates before the solve
         float* D = A.dbg;
-        if (ln == 0) { D[0] = (float)ncon; D[1] = (float)nefc; D[2] = (float)ne; D[3] = (float)nf; D[4] = (float)nl; D[5] = cost; D[6] = gradnorm; D[7] = (float)ngen; }
+        if (ln == 0) { D[0] = (float)(ncon + (CT ? npc : 0)); D[1] = (float)nefc; D[2] = (float)ne; D[3] = (float)nf; D[4] = (float)nl; D[5] = cost; D[6] = gradnorm; D[7] = (float)ngen; }
         if (ln < nbody) { for (int k = 0; k < 3; k++) D[64 + ln * 3 + k] = S.xpos[ln][k]; for (int k = 0; k < 4; k++) D[192 + ln * 4 + k] = S.xquat[ln][k]; }
         for (int e = ln; e < TRI; e += LW) D[512 + e] = S.M[dm.tri_row[e]][dm.tri_col[e]];
         if (ln < NV) { D[1100 + ln] = S.qsm[ln]; for (int q = 0; q < 6; q++) D[1200 + ln * 6 + q] = S.cdof[ln][q]; }
         D[1400 + ln] = (float)rtype[0]; D[1464 + ln] = rD[0]; D[1528 + ln] = raref[0]; D[1592 + ln] = rpos_dbg; D[1656 + ln] = Jaref[0];
         if (ln < ngen) for (int d = 0; d < NV; d++) D[2048 + ln * NV + d] = S.J[ln][d];
-        if (ln < MC) { D[1720 + ln] = ln < ncon ? S.cdist[ln] : 0.f; for (int k = 0; k < 3; k++) D[1740 + ln * 3 + k] = ln < ncon ? S.cpos[ln][k] : 0.f;
+        if (ln < MC && ln < 16) { D[1720 + ln] = ln < ncon ? S.cdist[ln] : 0.f; for (int k = 0; k < 3; k++) D[1740 + ln * 3 + k] = ln < ncon ? S.cpos[ln][k] : 0.f;
                        D[1900 + ln] = ln < ncon ? (float)S.cgeom[ln] : -1.f;
                        for (int k = 0; k < 3; k++) D[1920 + ln * 3 + k] = (NRM && ln < ncon) ? S.cnrm[NRM ? ln : 0][k] : (k == 2 ? 1.f : 0.f); }
+        // every contact (ground contacts, then -- CT -- the robot-robot ones): 8 floats each from D[4096]: dist, pos, normal, geom code
+        if (ln == 0) { D[11] = (float)ncon; D[12] = (float)npc; }
+        for (int c = ln; c < ncon + (CT ? npc : 0) && c < 512; c += LW) {
+          const bool gnd = !CT || c < ncon;
+          const int cp = CT ? c - ncon : 0;
+          float* o = D + 4096 + 8 * c;
+          o[0] = con_dist<CT>(S, gnd, c, cp);
+          for (int k = 0; k < 3; k++) {
+            o[1 + k] = con_pos<CT>(S, gnd, c, cp)[k];
+            o[4 + k] = NRM ? con_nrm<CT, NRM>(S, gnd, c, cp)[k] : (k == 2 ? 1.f : 0.f);
+          }
+          o[7] = (float)con_geom<CT>(S, gnd, c, cp);
+        }
       }
       // one Newton iteration after the search direction is known: exact line search, move, constraint update; false = stop
       auto newton_iterate = [&]() -> bool {
@@ -1463,6 +1698,21 @@ __global__ __launch_bounds__(64, (RPL == 1 && EPW == 1 && !HF) ? 4 : ((EPW == 1 
         for (int rr = 0; rr < RPL; rr++) {
           Jv[rr] = rowdot(S.sr, rr);
           q0[rr] = 0.5f * rD[rr] * Jaref[rr] * Jaref[rr]; q1[rr] = rD[rr] * Jaref[rr] * Jv[rr]; q2[rr] = 0.5f * rD[rr] * Jv[rr] * Jv[rr];
+        }
+        if constexpr (CT) {
+          // J s of the ground contacts from the bodies' twists of the search direction
+          body_twists(S.sr, nullptr, S.tw, nullptr);
+#pragma unroll
+          for (int cc = 0; cc < CPL; cc++) {
+            const int c = ln + LW * cc;
+            if (c < ncon) {
+              CGeo G;
+              cgeo(c, G);
+              float sn, s1, s2;
+              point_proj(S.tw[G.b], G, sn, s1, s2);
+              S.cJv[c][0] = sn + G.mu * s1; S.cJv[c][1] = sn - G.mu * s1; S.cJv[c][2] = sn + G.mu * s2; S.cJv[c][3] = sn - G.mu * s2;
+            }
+          }
         }
         const float snorm = sqrtf(grp_sum<LW>(sr_l * sr_l));
         if (!(snorm >= 1e-20f)) return false;
@@ -1479,6 +1729,23 @@ __global__ __launch_bounds__(64, (RPL == 1 && EPW == 1 && !HF) ? 4 : ((EPW == 1 
             c0 += inq ? q0[rr] : rh0[rr] - sf * Jaref[rr];
             c1 += inq ? q1[rr] : -sf * Jv[rr];
             c2 += inq ? q2[rr] : 0.f;
+          }
+          if constexpr (CT) {
+#pragma unroll
+            for (int cc = 0; cc < CPL; cc++) {
+              const int c = ln + LW * cc;
+              if (c < ncon) {
+                const float D = S.cD[c];
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                  const float ja = S.cJar[c][e], jv = S.cJv[c][e];
+                  const bool inq = ja + alpha * jv < 0.f;
+                  c0 += inq ? 0.5f * D * ja * ja : 0.f;
+                  c1 += inq ? D * ja * jv : 0.f;
+                  c2 += inq ? 0.5f * D * jv * jv : 0.f;
+                }
+              }
+            }
           }
           float C0 = grp_sum<LW>(c0) + gauss, C1 = grp_sum<LW>(c1) + qG1, C2 = grp_sum<LW>(c2) + qG2;
           Pnt p;
@@ -1567,6 +1834,16 @@ __global__ __launch_bounds__(64, (RPL == 1 && EPW == 1 && !HF) ? 4 : ((EPW == 1 
         Ma += alpha * Mv;
 #pragma unroll
         for (int rr = 0; rr < RPL; rr++) Jaref[rr] += alpha * Jv[rr];
+        if constexpr (CT) {
+#pragma unroll
+          for (int cc = 0; cc < CPL; cc++) {
+            const int c = ln + LW * cc;
+            if (c < ncon) {
+#pragma unroll
+              for (int e = 0; e < 4; e++) S.cJar[c][e] += alpha * S.cJv[c][e];
+            }
+          }
+        }
         if (ln < NV) S.qacc[ln] = qacc_l;
         const float oldcost = cost;
         update_constraint();
@@ -1622,17 +1899,27 @@ __global__ __launch_bounds__(64, (RPL == 1 && EPW == 1 && !HF) ? 4 : ((EPW == 1 
         bool hit = false;
         if (ln > 0 && ln < nbody && ((dm.term_bodymask >> ln) & 1u)) {
           float wr[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-          for (int c = 0; c < ncon; c++) {
-            const int gg = S.cgeom[c], g = gg & 0xff, g1 = (gg >> 8) - 1;
+          for (int c = 0; c < ncon + (CT ? npc : 0); c++) {
+            // CT: ground contacts (forces from their rows' J a - aref) first, then the robot-robot contacts (dense rows)
+            const bool gnd = !CT || c < ncon;
+            const int cp = CT ? c - ncon : 0;
+            const int gg = con_geom<CT>(S, gnd, c, cp), g = gg & 0xff, g1 = (gg >> 8) - 1;
             const bool on2 = dm.rec[g].g_body == ln, on1 = SC && g1 >= 0 && dm.rec[g1 >= 0 ? g1 : 0].g_body == ln;
             if (!on2 && !on1) continue;
             const float mu = (SC && g1 >= 0) ? fmaxf(MINMU, fmaxf(A.gext[g].w, A.gext[g1].w)) : S.p_gmu[g];
-            const float* f = &S.w.r.rowf[ne + 4 * c];
-            float nrm[3] = {NRM ? S.cnrm[NRM ? c : 0][0] : 0.f, NRM ? S.cnrm[NRM ? c : 0][1] : 0.f, NRM ? S.cnrm[NRM ? c : 0][2] : 1.f}, t1[3], t2[3];
+            float f[4];
+            for (int e = 0; e < 4; e++) f[e] = S.w.r.rowf[ne + 4 * (CT ? (gnd ? 0 : cp) : c) + e];
+            if constexpr (CT) {
+              if (gnd)
+                for (int e = 0; e < 4; e++) { const float x = S.cJar[c][e]; f[e] = x < 0.f ? -S.cD[c] * x : 0.f; }
+            }
+            const float* cn_ = con_nrm<CT, NRM>(S, gnd, c, cp);
+            const float* cp_ = con_pos<CT>(S, gnd, c, cp);
+            float nrm[3] = {NRM ? cn_[0] : 0.f, NRM ? cn_[1] : 0.f, NRM ? cn_[2] : 1.f}, t1[3], t2[3];
             make_frame(nrm, t1, t2);
             const float fl0 = f[0] + f[1] + f[2] + f[3], fl1 = (f[0] - f[1]) * mu, fl2 = (f[2] - f[3]) * mu;  // mj_contactForce, pyramidal
             float fw[3], dif[3], tq[3];
-            for (int k = 0; k < 3; k++) { fw[k] = nrm[k] * fl0 + t1[k] * fl1 + t2[k] * fl2; dif[k] = S.cpos[c][k] - com[k]; }
+            for (int k = 0; k < 3; k++) { fw[k] = nrm[k] * fl0 + t1[k] * fl1 + t2[k] * fl2; dif[k] = cp_[k] - com[k]; }
             cross(tq, dif, fw);
             const float sgn = on2 ? 1.f : -1.f;   // equal and opposite on geom1's body
             for (int k = 0; k < 3; k++) { wr[k] += sgn * tq[k]; wr[3 + k] += sgn * fw[k]; }
