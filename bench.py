@@ -38,7 +38,8 @@ WORKLOADS = {
     "light_rocky": ("flamingo_light_v1", "rocky_hard", False, 4096),
     "w4_rocky": ("w4_p_v2", "rocky_hard", True, 4096),            # configs[2]
     "p_v3_flat": ("flamingo_p_v3", "flat", False, 4096),          # configs[3] per-GPU shard (flat; its terrain is not named)
-    "humanoid_flat": ("humanoid_p_v0", "flat", False, 1024),      # configs[4] per-GPU shard on flat (stairs need more rows)
+    "humanoid_flat": ("humanoid_p_v0", "flat", False, 1024),
+    "humanoid_stairs": ("humanoid_p_v0", "stairs_up_hard", False, 1024),   # configs[4] per-GPU shard: position-command mode, targets U([-3,3]^2)
 }
 
 
@@ -238,7 +239,10 @@ def main(argv=None):
     if n % S:
         raise SystemExit(f"--streams {S} must divide the envs per GPU ({n})")
     ns = n // S
-    cfg = make_config(robot, terrain=terrain, num_envs=ns, seed=1234, height_map=hmap)
+    poscmd = args.workload == "humanoid_stairs"
+    cfg = make_config(robot, terrain=terrain, num_envs=ns, seed=1234, height_map=hmap, position_command=poscmd)
+    if poscmd:
+        cfg["observation"]["command_dim"] = 2                        # envs/wrappers.py:357
     # S = 1: one launch per fleet step.  S > 1: the fleet as S independent shards (own engine handle, own HIP stream, global env
     # ids unchanged), so a shard's next control step fills the tail of the others' launches.
     envs = [BatchedEnv(cfg, num_envs=ns, device=local, seed=1234, auto_reset=True, env_id0=env_id0 + i * ns, gain_noise=0.1) for i in range(S)]
@@ -253,7 +257,12 @@ def main(argv=None):
     reporters = [FleetReporter(e) for e in envs]
     for i, e in enumerate(envs):
         with torch.cuda.stream(streams[i]):
-            e.receive_user_command(np.array([0.5, 0.0, 0.0, 0.0], dtype=np.float32))
+            if poscmd:   # per-env targets U([-3, 3]^2), keyed by global env id
+                from cosim_amd import rng as crng
+                gids = np.arange(env_id0 + i * ns, env_id0 + (i + 1) * ns, dtype=np.uint64)[:, None]
+                e.receive_user_command((6.0 * crng.uniform(1234, gids, 0, 6, np.arange(2)[None, :]) - 3.0).astype(np.float32))
+            else:
+                e.receive_user_command(np.array([0.5, 0.0, 0.0, 0.0], dtype=np.float32)[:max(e.command_dim, 1)])
             e.reset()
             for t in range(args.warmup):
                 e.step(actions[i][t])
@@ -317,7 +326,8 @@ def main(argv=None):
                        "fleet_samples": fleet["action_diff_RMSE"]["count"], "fleet_abs_torque_0": fleet["abs_torque_0"]["mean"],
                        "solver_per_substep": {"rows": st["rows"] / nsub, "newton_iters": st["newton_iters"] / nsub,
                                               "ls_evals": st["ls_evals"] / nsub, "factorisations": st["factorisations"] / nsub},
-                       "nan_resets": st["nan_resets"]},
+                       "nan_resets": st["nan_resets"], "dropped_contacts": st["dropped_contacts"], "dropped_limit_rows": st["dropped_limit_rows"],
+                       "max_contacts_per_env": max(x["max_contacts"] for x in sts), "contact_slots": env.engine.query("contact_slots")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, **pmc_traffic(args.workload),
                          "kernel": f"cosim::env_kernel<{env.nv},{env.cm.blob.nbody},...>", "kernel_ms": kernel_ms, "launches": launches,

@@ -438,15 +438,8 @@ int cosim_create(const cosim_model_t* model, const float* hull_vert, const int* 
     HIP_TRY(hipMemcpy(e->d_gext, hg.data(), hg.size() * sizeof(float4), hipMemcpyHostToDevice));
   }
   if (model->ground_type == CS_GEOM_HFIELD) {
-    // mjc_ConvexHField walks every cell under a geom's bounding box and emits up to 50 contacts per geom; the kernel walks at
-    // most HF_MAXCELLS x HF_MAXCELLS cells and holds 12-16 contacts per env, so fields that are fine against the geoms
-    // (the stairs_* terrains: 1 cm cells) are refused instead of being simulated with a truncated contact set
-    const double cell = fmin(2.0 * model->hfield_size[0] / (model->hfield_ncol - 1), 2.0 * model->hfield_size[1] / (model->hfield_nrow - 1));
-    for (int g = 0; g < model->ngeom; g++)
-      if (model->geom_ground[g] && 2.0 * model->geom_rbound[g] / cell + 2.0 > (double)HF_MAXCELLS) {
-        delete e;
-        return fail(COSIM_EINVAL, "cosim_create: heightfield cells are too fine for the robot's geoms (stairs-class terrain): not supported");
-      }
+    // any cell size: the narrowphase walks however many prisms lie under a geom (1 cm cells of the stairs_* terrains included);
+    // contacts beyond the kernel variant's slots are counted (cosim_get "meta", word 8), never dropped silently
     if (!hfield) return fail(COSIM_EINVAL, "cosim_create: heightfield ground but no elevation data was passed");
     size_t nh = (size_t)model->hfield_nrow * model->hfield_ncol;
     HIP_TRY(hipMalloc(&e->d_hfield, nh * sizeof(float)));

@@ -215,6 +215,10 @@ struct CtLds {
   float cD[MC], cJar[MC][4], cJv[MC][4];
   float tw[NB][6], bw[NB][6], bW[NB][21];
   unsigned cbmask;   // bodies that carry a ground contact
+  // heightfield narrowphase, per geom: end of its (geom, prism) work items in the flattened list, contacts found so far, sub-grid
+  // origin, prisms per strip row, lowest point of the geom
+  int hf_end[24], hf_cnt[24], hf_cmin[24], hf_rmin[24], hf_ppr[24];
+  float hf_lo[24];
 };
 template <int NB, int MC, int MCP>
 struct CtLds<false, NB, MC, MCP> {};
@@ -478,6 +482,7 @@ __global__ __launch_bounds__(64, (RPL == 1 && EPW == 1 && !HF) ? 4 : ((EPW == 1 
   if (env >= A.n_envs) return;
   const DevModel& dm = *A.dm;
   const DevObs& ob = *A.ob;
+  const HullGraph HG{A.hull_vert, A.hull_adr, A.hull_nbr};
   const Layout lay = A.lay;
   float* rec = A.state + (size_t)env * lay.s_stride;
   const float* par = A.params + (size_t)env * lay.p_stride;
@@ -861,6 +866,27 @@ __global__ __launch_bounds__(64, (RPL == 1 && EPW == 1 && !HF) ? 4 : ((EPW == 1 
       // =========================================================== collision: ground (plane or heightfield) vs robot geoms
       int ncon = 0;
       int npc = 0;   // CT: robot-robot contacts (slots of their own, dense rows); otherwise they follow the ground contacts in ncon
+      // world pose of geom g as a convex object (mesh: body frame, vertices in body coordinates; primitive: geom frame)
+      auto make_cobj = [&](CObj& o, int g) {
+        const LaneRec& G = dm.rec[g];
+        const int gb = G.g_body;
+        const float bq[4] = {S.xquat[gb][0], S.xquat[gb][1], S.xquat[gb][2], S.xquat[gb][3]};
+        const float4 ge = A.gext[g];
+        const float cl[3] = {ge.x, ge.y, ge.z};
+        float v[3];
+        qrot(v, bq, cl);
+        for (int k = 0; k < 3; k++) o.center[k] = S.xpos[gb][k] + v[k];
+        o.kind = G.g_type; o.adr = G.g_hulladr; o.num = G.g_hullnum; o.hint = 0;
+        for (int k = 0; k < 3; k++) o.size[k] = G.g_size[k];
+        if (G.g_type == CS_GEOM_MESH) {
+          for (int k = 0; k < 3; k++) o.pos[k] = S.xpos[gb][k];
+          for (int k = 0; k < 4; k++) o.q[k] = bq[k];
+        } else {
+          qrot(v, bq, G.g_pos);
+          for (int k = 0; k < 3; k++) o.pos[k] = S.xpos[gb][k] + v[k];
+          qmul(o.q, bq, G.g_quat);
+        }
+      };
       {
         const LaneRec& R = dm.rec[ln];
         constexpr bool is_plane = !HF;
@@ -923,41 +949,114 @@ __global__ __launch_bounds__(64, (RPL == 1 && EPW == 1 && !HF) ? 4 : ((EPW == 1 
           }
           ncon = total;
         } else {
-          // heightfield (mjc_ConvexHField): primitives lane-parallel, contacts appended through an LDS counter
-          if (ln == 0) S.ncon_ctr = 0;
-          WSYNC();
-          // lowest point of the body-frame box around the geom vs the highest terrain vertex under its bounding sphere
-          bool near = false;
-          if (active) {
-            float m[9];
-            q2m(m, xq);
-            const float low = ctr[2] - (fabsf(m[6]) * R.g_half[0] + fabsf(m[7]) * R.g_half[1] + fabsf(m[8]) * R.g_half[2]);
-            near = low - margin <= terrain_max_under(T, ctr, rb);
-          }
-          if (near) {
-            if (gt == CS_GEOM_MESH) mesh_near = true;
-            else if constexpr ((GTM & ~GT_MESH) != 0) {
-              CObj o;
-              o.kind = gt; o.adr = 0; o.num = 0;
-              for (int k = 0; k < 3; k++) o.size[k] = R.g_size[k];
-              {
-                float v[3];
-                qrot(v, xq, R.g_pos);
-                for (int k = 0; k < 3; k++) { o.pos[k] = xp[k] + v[k]; o.center[k] = o.pos[k]; }
-                qmul(o.q, xq, R.g_quat);
-              }
-              hfield_geom<GTM, false>(T, o, ctr, rb, margin, dm.hfield_size[3], A.hull_vert, ln, [&](float dist, const float* pos, const float* n) {
-                const int slot = atomicAdd(&S.ncon_ctr, 1);
-                if (slot < MC) {
-                  S.cdist[slot] = dist;
-                  S.cgeom[slot] = ln;
-                  for (int k = 0; k < 3; k++) { S.cpos[slot][k] = pos[k]; S.cnrm[NRM ? slot : 0][k] = n[k]; }
+          // heightfield (mjc_ConvexHField).  Every (geom, prism) pair is one work item; the items of all geoms form one list in
+          // (geom, strip) order -- MuJoCo's order -- and are dealt to the lanes 64 at a time: each lane runs its own MPR (primitive
+          // supports are O(1), hull supports climb the neighbour graph).  A geom keeps its first mjMAXCONPAIR = 50 penetrating
+          // prisms.  The walk is a loop over however many prisms lie under the geoms: 1 cm stairs cells cost passes, not slots.
+          static_assert(!HF || CT, "heightfield kernels run in contact-twist mode");
+          if constexpr (CT) {
+            if (ln == 0) S.ncon_ctr = 0;
+            int n_items = 0;
+            if (active) {
+              // phase A (lane = geom): MuJoCo's early outs, then the sub-grid under the geom's axis-aligned box
+              CObj og;
+              make_cobj(og, ln);
+              const float base_ = dm.hfield_size[3];
+              const double lx = (double)ctr[0] + T.ox, ly = (double)ctr[1] + T.oy;
+              bool out = !(fabsf(ctr[0]) + fabsf(ctr[1]) + fabsf(ctr[2]) < 1e8f) ||   // non-finite pose (the env is reset at the end of the step)
+                         (double)T.sx < lx - rb - margin || -(double)T.sx > lx + rb + margin || (double)T.sy < ly - rb - margin ||
+                         -(double)T.sy > ly + rb + margin || T.sz < ctr[2] - T.gz - rb - margin || -base_ > ctr[2] - T.gz + rb + margin;
+              if (!out) {
+                float lo[3], hi[3];
+#pragma unroll
+                for (int k = 0; k < 3; k++) {
+                  float d[3] = {0.f, 0.f, 0.f}, p_[3];
+                  d[k] = 1.f;
+                  cobj_support<GTM, false>(og, HG, d, p_, ln);
+                  hi[k] = p_[k];
+                  d[k] = -1.f;
+                  cobj_support<GTM, false>(og, HG, d, p_, ln);
+                  lo[k] = p_[k];
                 }
-              });
+                const double x0 = (double)lo[0] + T.ox, x1 = (double)hi[0] + T.ox, y0 = (double)lo[1] + T.oy, y1 = (double)hi[1] + T.oy;
+                out = x0 - margin > T.sx || x1 + margin < -T.sx || y0 - margin > T.sy || y1 + margin < -T.sy || lo[2] - T.gz - margin > T.sz ||
+                      hi[2] - T.gz + margin < -base_;
+                if (!out) {
+                  int cmin = (int)floor((x0 + T.sx) / T.dx), cmax = (int)ceil((x1 + T.sx) / T.dx);
+                  int rmin = (int)floor((y0 + T.sy) / T.dy), rmax = (int)ceil((y1 + T.sy) / T.dy);
+                  cmin = max(cmin, 0); rmin = max(rmin, 0); cmax = min(cmax, T.ncol - 1); rmax = min(rmax, T.nrow - 1);
+                  const int ppr = 2 * (cmax - cmin + 1) - 2;   // prisms per strip row: consecutive vertex triples of 2 ncols strip vertices
+                  if (ppr > 0 && (rmax - rmin) * ppr > 32768) { rmax = rmin + 32768 / ppr; st_dropcon++; }   // bounded walk (a 0.6 m x 0.6 m footprint of 1 cm cells fits); counted
+                  if (rmax > rmin && ppr > 0) {
+                    n_items = (rmax - rmin) * ppr;
+                    S.hf_cmin[ln] = cmin; S.hf_rmin[ln] = rmin; S.hf_ppr[ln] = ppr; S.hf_lo[ln] = lo[2];
+                  }
+                }
+              }
             }
+            int end = n_items;   // inclusive prefix sum over the geom lanes
+#pragma unroll
+            for (int o = 1; o < 32; o <<= 1) { const int t = __shfl_up(end, o, 64); if (ln >= o) end += t; }
+            if (ln < 24) { S.hf_end[ln] = end; S.hf_cnt[ln] = 0; }
+            const int total = __shfl(end, 23, 64);   // lanes past ngeom add nothing
+            WSYNC();
+            int base = 0;
+            while (base < total) {
+              int g0 = 0;
+              while (base >= S.hf_end[g0]) g0++;   // uniform; terminates: base < total = hf_end[23]
+              if (S.hf_cnt[g0] >= 50) { base = S.hf_end[g0]; continue; }   // this geom has its 50 contacts: skip the rest of its prisms
+              const int item = base + ln;
+              bool hit = false;
+              int g = g0;
+              float depth = 0.f, nrm_[3] = {0.f, 0.f, 1.f}, pos_[3] = {0.f, 0.f, 0.f}, gmargin = 0.f;
+              if (item < total) {
+                while (item >= S.hf_end[g]) g++;
+                const int k = item - (g > 0 ? S.hf_end[g > 0 ? g - 1 : 0] : 0), ppr = S.hf_ppr[g], rrow = k / ppr, kk = k - rrow * ppr;
+                const int r = S.hf_rmin[g] + rrow, cmin = S.hf_cmin[g];
+                gmargin = dm.rec[g].g_margin;
+                PrismObj P;
+                P.zb = T.gz - dm.hfield_size[3];
+#pragma unroll
+                for (int i = 0; i < 3; i++) {   // strip vertex kk + i: column cmin + (v >> 1), row r + 1 for even v, r for odd v
+                  const int v = kk + i, c = cmin + (v >> 1), rr = r + 1 - (v & 1);
+                  P.x[i] = (float)(c * T.dx - (double)T.sx - T.ox);
+                  P.y[i] = (float)(rr * T.dy - (double)T.sy - T.oy);
+                  P.zt[i] = T.data[rr * T.ncol + c] * T.sz + T.gz + gmargin;
+                }
+                const float lo2 = S.hf_lo[g];
+                if (!(P.zt[0] < lo2 && P.zt[1] < lo2 && P.zt[2] < lo2) && S.hf_cnt[g] < 50) {
+                  CObj o;
+                  make_cobj(o, g);
+                  const float c1[3] = {(P.x[0] + P.x[1] + P.x[2]) * (1.f / 3.f), (P.y[0] + P.y[1] + P.y[2]) * (1.f / 3.f),
+                                       (P.zt[0] + P.zt[1] + P.zt[2] + 3.f * P.zb) * (1.f / 6.f)};
+                  const MprPrismGeom<GTM, false> sup{P, o, HG, ln};
+                  hit = mpr_penetration(sup, c1, o.center, depth, nrm_, pos_) && (nrm_[0] != 0.f || nrm_[1] != 0.f || nrm_[2] != 0.f);
+                }
+              }
+              // ordered append: rank of a hit among the hits of its own geom (items are in (geom, strip) order, so lane order is it)
+              int rank_g = 0;
+              for (unsigned long long rest = __ballot(hit); rest;) {
+                const int gs = __shfl(g, __builtin_ctzll(rest), 64);
+                const unsigned long long same = __ballot(hit && g == gs);
+                if (hit && g == gs) rank_g = __popcll(same & lanemask_lt(ln));
+                rest &= ~same;
+              }
+              const bool keep = hit && S.hf_cnt[g] + rank_g < 50;
+              const unsigned long long km = __ballot(keep);
+              const int slot = S.ncon_ctr + __popcll(km & lanemask_lt(ln));
+              if (keep && slot < MC) {
+                S.cdist[slot] = gmargin - depth;
+                S.cgeom[slot] = g;
+                for (int k = 0; k < 3; k++) { S.cpos[slot][k] = pos_[k]; S.cnrm[NRM ? slot : 0][k] = nrm_[k]; }
+              }
+              WSYNC();   // every lane has read the counters
+              if (keep) atomicAdd(&S.hf_cnt[g], 1);
+              if (ln == 0) S.ncon_ctr += __popcll(km);
+              WSYNC();
+              base += 64;
+            }
+            ncon = S.ncon_ctr;
           }
-          WSYNC();
-          ncon = S.ncon_ctr;
         }
         // convex meshes near the ground, one at a time, all lanes sharing the scans over the hull's vertices
         unsigned long long mm = grp_ballot<LW>(mesh_near, hb);
@@ -975,28 +1074,6 @@ __global__ __launch_bounds__(64, (RPL == 1 && EPW == 1 && !HF) ? 4 : ((EPW == 1 
             float v[3];
             qrot(v, gq, G.g_rcenter);
             for (int k = 0; k < 3; k++) gctr[k] = gxp[k] + v[k];
-          }
-          if constexpr (!is_plane) {
-            CObj o;
-            o.kind = CS_GEOM_MESH; o.adr = adr; o.num = num;
-            for (int k = 0; k < 3; k++) { o.size[k] = 0.f; o.pos[k] = gxp[k]; }
-            for (int k = 0; k < 4; k++) o.q[k] = gq[k];
-            {
-              const float4 ge = A.gext[g];
-              const float cl[3] = {ge.x, ge.y, ge.z};
-              float v[3];
-              qrot(v, gq, cl);
-              for (int k = 0; k < 3; k++) o.center[k] = gxp[k] + v[k];
-            }
-            hfield_geom<GTM, true>(T, o, gctr, grb, gmargin, dm.hfield_size[3], A.hull_vert, ln, [&](float dist, const float* pos, const float* n) {
-              if (ncon < MC && ln == 0) {
-                S.cdist[ncon] = dist;
-                S.cgeom[ncon] = g;
-                for (int k = 0; k < 3; k++) { S.cpos[ncon][k] = pos[k]; S.cnrm[NRM ? ncon : 0][k] = n[k]; }
-              }
-              ncon++;
-            });
-            continue;
           }
           // plane: mjc_PlaneConvex -- the support vertex, then its hull neighbours within the margin (at most 4 contacts)
           const float P0[3] = {0.f, 0.f, T.gz}, n[3] = {0.f, 0.f, 1.f};
@@ -1049,26 +1126,6 @@ __global__ __launch_bounds__(64, (RPL == 1 && EPW == 1 && !HF) ? 4 : ((EPW == 1 
         // =========================================================== robot-robot pairs (mjc_Convex: one MPR contact per pair)
         // candidates: the compiled pair list (contype/conaffinity, same-body, parent-child and <exclude> filters applied)
         // cut down by bounding spheres; primitive pairs run lane-parallel, pairs with a mesh one at a time wave-wide
-        auto make_cobj = [&](CObj& o, int g) {
-          const LaneRec& G = dm.rec[g];
-          const int gb = G.g_body;
-          const float bq[4] = {S.xquat[gb][0], S.xquat[gb][1], S.xquat[gb][2], S.xquat[gb][3]};
-          const float4 ge = A.gext[g];
-          const float cl[3] = {ge.x, ge.y, ge.z};
-          float v[3];
-          qrot(v, bq, cl);
-          for (int k = 0; k < 3; k++) o.center[k] = S.xpos[gb][k] + v[k];
-          o.kind = G.g_type; o.adr = G.g_hulladr; o.num = G.g_hullnum;
-          for (int k = 0; k < 3; k++) o.size[k] = G.g_size[k];
-          if (G.g_type == CS_GEOM_MESH) {
-            for (int k = 0; k < 3; k++) o.pos[k] = S.xpos[gb][k];
-            for (int k = 0; k < 4; k++) o.q[k] = bq[k];
-          } else {
-            qrot(v, bq, G.g_pos);
-            for (int k = 0; k < 3; k++) o.pos[k] = S.xpos[gb][k] + v[k];
-            qmul(o.q, bq, G.g_quat);
-          }
-        };
         auto pair_put = [&](int slot, float dist, int code, const float* pp, const float* nn) {
           if constexpr (CT) {
             if (slot < L::MCP) {
@@ -1129,7 +1186,7 @@ __global__ __launch_bounds__(64, (RPL == 1 && EPW == 1 && !HF) ? 4 : ((EPW == 1 
               CObj o1, o2;
               make_cobj(o1, g1);
               make_cobj(o2, g2);
-              const MprPair<GTM, false> sup{o1, o2, A.hull_vert, ln};
+              const MprPair<GTM, false> sup{o1, o2, HG, ln};
               hit = mpr_penetration(sup, o1.center, o2.center, depth, cn, cp) && (cn[0] != 0.f || cn[1] != 0.f || cn[2] != 0.f);
             }
           }
@@ -1148,7 +1205,7 @@ __global__ __launch_bounds__(64, (RPL == 1 && EPW == 1 && !HF) ? 4 : ((EPW == 1 
               CObj o1, o2;
               make_cobj(o1, h1);
               make_cobj(o2, h2);
-              const MprPair<GTM, true> sup{o1, o2, A.hull_vert, ln};
+              const MprPair<GTM, true> sup{o1, o2, HG, ln};
               float dep2 = 0.f, n2[3] = {0.f, 0.f, 1.f}, c2[3] = {0.f, 0.f, 0.f};
               const bool hit2 = mpr_penetration(sup, o1.center, o2.center, dep2, n2, c2) && (n2[0] != 0.f || n2[1] != 0.f || n2[2] != 0.f);
               if (hit2) {
@@ -1204,7 +1261,8 @@ __global__ __launch_bounds__(64, (RPL == 1 && EPW == 1 && !HF) ? 4 : ((EPW == 1 
       }
       const int ndc = CT ? npc : ncon;      // contacts with dense rows
       const int ngen = ne + 4 * ndc;        // general rows (dense J): equality + contact
-      const int nefc = ngen + nf + nl + (CT ? 4 * ncon : 0);   // then unit rows (frictionloss, limits); CT: + the ground contacts' rows
+      const int nrow = ngen + nf + nl;      // then unit rows (frictionloss, limits): the rows that live one per lane slot
+      const int nefc = nrow + (CT ? 4 * ncon : 0);   // CT: + the ground contacts' rows (twist space, not lane slots)
       WSYNC();
 
       // per-lane row state: row (ln + LW rr), rr < RPL
@@ -1282,7 +1340,7 @@ __global__ __launch_bounds__(64, (RPL == 1 && EPW == 1 && !HF) ? 4 : ((EPW == 1 
               rvel += v * S.qvel[j];   // J qvel over the dofs the row touches
             }
           }
-        } else if (row < nefc) {
+        } else if (row < nrow) {
           if (row < ngen + nf) {
             rtype[rr] = RT_FRIC;
             rdof[rr] = dm.rec[row - ngen].d_fric;  // model-level list; a per-env value of zero leaves the row inert

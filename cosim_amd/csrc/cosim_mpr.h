@@ -27,7 +27,10 @@ struct CObj {            // one convex geom, world pose
   float size[3];
   int adr, num;          // mesh: slice of the hull vertex array
   float center[3];       // mjccd_center
+  mutable int hint;      // mesh, lane-serial support: vertex the next hill climb starts from (the previous answer)
 };
+// hull neighbour graph (CSR over the hull vertex array), for the lane-serial mesh support
+struct HullGraph { const float* vert; const int* adr; const int* nbr; };
 typedef double real;   // the portal arithmetic runs in fp64 (ill-conditioned for edge contacts); supports are fp32
 __device__ __forceinline__ real mpr_dot(const real* a, const real* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
 __device__ __forceinline__ void mpr_cross(real* r, const real* a, const real* b) {
@@ -52,13 +55,42 @@ __device__ __forceinline__ real mpr_normalize(real* v) {
   return n;
 }
 
+// Support vertex of a convex hull by hill climbing on its neighbour graph (what MuJoCo's mesh support does on large hulls, there
+// too from the previous answer): on a convex polytope a vertex that is not a maximiser of l . v has a strictly better neighbour,
+// so the climb ends on a maximiser after O(sqrt(n)) steps instead of an n-vertex scan.  One lane, no cooperation: used where every
+// lane runs its own query.  Ties (a face orthogonal to l) end on whichever maximiser the path reaches first.
+__device__ __forceinline__ int hull_climb(const HullGraph& H, int adr, int num, int start, const float* l) {
+  int cur = (start >= 0 && start < num) ? start : 0;
+  const float* v = H.vert + 3 * (adr + cur);
+  float best = l[0] * v[0] + l[1] * v[1] + l[2] * v[2];
+  for (int it = 0; it < num; it++) {   // bounded: every step moves to a strictly better vertex
+    const int lo = H.adr[adr + cur], hi = H.adr[adr + cur + 1];
+    int nxt = cur;
+    for (int e = lo; e < hi; e++) {
+      const int i = H.nbr[e];
+      const float* w = H.vert + 3 * (adr + i);
+      const float t = l[0] * w[0] + l[1] * w[1] + l[2] * w[2];
+      if (t > best) { best = t; nxt = i; }
+    }
+    if (nxt == cur) break;
+    cur = nxt;
+  }
+  return cur;
+}
+
 // mjccd_support: furthest point of the geom along the unit world direction
 template <int GTM, bool COOP>
-__device__ __forceinline__ void cobj_support(const CObj& o, const float* hull, const float* dir, float* out, int ln) {
+__device__ __forceinline__ void cobj_support(const CObj& o, const HullGraph& H, const float* dir, float* out, int ln) {
+  const float* hull = H.vert;
   const float qi[4] = {o.q[0], -o.q[1], -o.q[2], -o.q[3]};
   float l[3], r[3] = {0.f, 0.f, 0.f};
   qrot(l, qi, dir);
-  if (COOP && (GTM & GT_MESH) && o.kind == CS_GEOM_MESH) {
+  if (!COOP && (GTM & GT_MESH) && o.kind == CS_GEOM_MESH) {
+    const int bi = hull_climb(H, o.adr, o.num, o.hint, l);
+    o.hint = bi;
+    const float* v = hull + 3 * (o.adr + bi);
+    r[0] = v[0]; r[1] = v[1]; r[2] = v[2];
+  } else if (COOP && (GTM & GT_MESH) && o.kind == CS_GEOM_MESH) {
     float best = -3.0e38f;
     int besti = 0x7fffffff;
     for (int i = ln; i < o.num; i += 64) {
@@ -90,7 +122,7 @@ __device__ __forceinline__ void cobj_support(const CObj& o, const float* hull, c
 template <int GTM, bool COOP>
 struct MprPair {
   const CObj &a, &b;
-  const float* hull;
+  const HullGraph& hull;
   int ln;
   __device__ __forceinline__ void operator()(const real* dir, MprSup& s) const {   // __ccdSupport
     const float fd[3] = {(float)dir[0], (float)dir[1], (float)dir[2]}, nd[3] = {-fd[0], -fd[1], -fd[2]};
@@ -285,7 +317,7 @@ template <int GTM, bool COOP>
 struct MprPrismGeom {
   const PrismObj& P;
   const CObj& g;
-  const float* hull;
+  const HullGraph& hull;
   int ln;
   __device__ __forceinline__ void operator()(const real* dir, MprSup& s) const {
     const float fd[3] = {(float)dir[0], (float)dir[1], (float)dir[2]}, nd[3] = {-fd[0], -fd[1], -fd[2]};
@@ -300,7 +332,7 @@ struct MprPrismGeom {
 // base's offset on the field in fp64.  emit(dist, pos, normal) is called once per penetrated prism, in strip order.
 template <int GTM, bool COOP, class EMIT>
 __device__ __forceinline__ void hfield_geom(const Terrain& T, const CObj& o, const float* ctr, float rb, float margin, float base,
-                                            const float* hull, int ln, const EMIT& emit) {
+                                            const HullGraph& hull, int ln, const EMIT& emit) {
   // box-sphere early outs
   const double lx = (double)ctr[0] + T.ox, ly = (double)ctr[1] + T.oy;
   if ((double)T.sx < lx - rb - margin || -(double)T.sx > lx + rb + margin || (double)T.sy < ly - rb - margin || -(double)T.sy > ly + rb + margin) return;

@@ -580,12 +580,96 @@ def test_self_collision_mpr_matches_oracle(env_id, steps, amp):
     env.close()
 
 
-def test_stairs_class_heightfield_is_refused_loudly():
-    """1 cm heightfield cells (stairs_*): mjc_ConvexHField would emit up to 50 contacts per geom, beyond the engine's rows."""
+def _stairs_states(o, b, q0, rng, spots, steps, amp):
+    R = dict(qpos=[], qvel=[], warm=[], act=[], qpos1=[], qvel1=[], ncon=[], tq=[])
+    for spot in range(spots):
+        q = q0.copy()
+        q[0:2] = rng.uniform(-3.5, 3.5, size=2)                          # anywhere in the pit: floor, treads, risers' edges
+        yaw = rng.uniform(-np.pi, np.pi)
+        q[3:7] = [np.cos(yaw / 2), 0, 0, np.sin(yaw / 2)]
+        q[2] = q0[2] + (10.0 - o.ray_down(q[0], q[1], 10.0)) + 0.02
+        o.reset(q)
+        for t in range(steps):
+            a = np.clip(amp * rng.normal(size=b.nu), -1, 1)
+            R["qpos"].append(o.qpos.copy()); R["qvel"].append(o.qvel.copy()); R["warm"].append(o.qacc_warmstart.copy()); R["act"].append(a)
+            tq = o.control_step(a)
+            R["qpos1"].append(o.qpos.copy()); R["qvel1"].append(o.qvel.copy()); R["ncon"].append(o.ncon); R["tq"].append(tq)
+            assert not o.bad
+    return {k: np.array(v) for k, v in R.items()}
+
+
+def test_humanoid_on_stairs_up_hard_with_position_command():
+    """BASELINE config 5: humanoid_p_v0 on stairs_up_hard (1024 x 1024 cells of 1 cm: mjc_ConvexHField emits up to 50 contacts per
+    geom, about 100 for the standing robot and several hundred once it lies on the steps), position-command mode (wrappers.py:356-375).
+    One-control-step replay of oracle states from standing to fallen, prism contact sets against the oracle, the applied position
+    command in the state vector, and the capacity counter (nothing is left out below the kernel's 256 ground-contact slots)."""
+    import torch
     from cosim_amd.batched_env import BatchedEnv
+    from cosim_amd.compile import compile_model
     from cosim_amd.config import PARITY_RANDOM, make_config
-    with pytest.raises((ValueError, RuntimeError), match="stairs"):
-        BatchedEnv(make_config("flamingo_light_v1", terrain="stairs_up_easy", random=PARITY_RANDOM), num_envs=2)
+    from cosim_amd.model import get_field
+    from oracle.oracle import Oracle
+    cfg = make_config("humanoid_p_v0", terrain="stairs_up_hard", random=PARITY_RANDOM, position_command=True)
+    cfg["observation"]["command_dim"] = 2                                # what the GUI requires for position_command (wrappers.py:357)
+    cm = compile_model(cfg)
+    b = cm.blob
+    assert b.ground_type == 1 and cm.hfield.shape == (1024, 1024) and abs(b.hfield_size[0] - 5.0) < 1e-12
+    o = Oracle(cm)
+    q0 = np.array(get_field(b, "init_qpos")[:b.nq])
+    R = _stairs_states(o, b, q0, np.random.default_rng(21), spots=16, steps=40, amp=0.5)
+    n = len(R["qpos"])
+    slots = 256
+    fits = R["ncon"] <= slots
+    assert R["ncon"].max() >= 100 and np.quantile(R["ncon"], 0.5) >= 20 and fits.mean() > 0.95
+    env = BatchedEnv(cfg, num_envs=n, auto_reset=False, compiled=cm)
+    assert env.engine.query("contact_slots") == slots and env.state_dim == 3 * 78 + 2
+    target = np.random.default_rng(4).uniform(-3, 3, size=(n, 2)).astype(np.float32)
+    env.receive_user_command(target)
+    env.reset()
+    env.set_state(R["qpos"], R["qvel"], R["warm"])
+    state, _, _, info = env.step(torch.tensor(R["act"], dtype=torch.float32, device=env.device))
+    d = env.get_data()
+    qp, qv = d.qpos.cpu().numpy().astype(np.float64), d.qvel.cpu().numpy().astype(np.float64)
+    np.testing.assert_allclose(info["torque"].cpu().numpy(), R["tq"], rtol=1e-4, atol=2e-3)
+    st = env.solver_stats()
+    assert st["dropped_contacts"] == int(np.maximum(R["ncon"] - slots, 0).sum()) or st["dropped_contacts"] <= 4 * int((~fits).sum()) + 8
+    if fits.all():
+        assert st["dropped_contacts"] == 0
+    assert abs(st["max_contacts"] - R["ncon"].max()) <= 3
+    ep = np.abs(qp - R["qpos1"])[fits].max(axis=1)
+    ev = np.abs(qv - R["qvel1"])[fits].max(axis=1)
+    # prism ridges (every stair edge) are where fp32 / fp64 MPR portals can land on either face: judged by quantile
+    assert np.median(ep) < 2e-5 and np.quantile(ep, 0.9) < 3e-4, (np.median(ep), np.quantile(ep, 0.9), ep.max())
+    assert np.median(ev) < 2e-3 and np.quantile(ev, 0.9) < 4e-2, (np.median(ev), np.quantile(ev, 0.9), ev.max())
+    # position command: R(-yaw) (target - base_xy) from the PRE-step pose, written into the two command slots (last two entries)
+    got = state[:, -2:].cpu().numpy().astype(np.float64)
+    for e in range(0, n, 7):
+        w, x, y, z = R["qpos"][e][3:7]
+        yaw = np.arctan2(2 * (w * z + x * y), 1 - 2 * (y * y + z * z))
+        dxy = target[e].astype(np.float64) - R["qpos"][e][:2]
+        c, s_ = np.cos(-yaw), np.sin(-yaw)
+        np.testing.assert_allclose(got[e], [c * dxy[0] - s_ * dxy[1], s_ * dxy[0] + c * dxy[1]], atol=2e-5)
+    # narrowphase parity on the stairs: same prisms hit per geom, same depth / normal
+    env.set_state(R["qpos"], R["qvel"], R["warm"])
+    same_set = tight = total = 0
+    sample = [w for w in range(0, n, 9) if 0 < R["ncon"][w] <= slots]
+    for w in sample:
+        o.reset(R["qpos"][w], R["qvel"][w])
+        o.forward()
+        oc = o.contacts()
+        dbg = env.engine.debug_forward(int(w))
+        base = R["qpos"][w][:3].copy(); base[2] = 0.0
+        key = lambda c: (c[0], round(float(c[2][0]), 3), round(float(c[2][1]), 3))
+        gl = sorted([(gg & 255, gd, gp + base, gn) for gg, gd, gp, gn in _dbg_contacts(dbg) if (gg >> 8) == 0], key=key)
+        ol = sorted([(int(c[7]), c[0], c[1:4], c[4:7]) for c in oc if c[9] < 0], key=key)
+        if len(gl) != len(ol) or any(a[0] != c[0] for a, c in zip(gl, ol)):
+            continue
+        same_set += 1
+        for a, c in zip(gl, ol):
+            total += 1
+            tight += abs(a[1] - c[1]) < 3e-5 and np.abs(a[3] - c[3]).max() < 3e-3 and np.abs(a[2] - c[2]).max() < 3e-3
+    assert same_set >= 0.85 * len(sample) and total >= 300 and tight >= 0.9 * total, (same_set, len(sample), tight, total)
+    env.close()
 
 
 def test_cli_rollout_with_onnx_policy_on_device(tmp_path):

@@ -11,6 +11,6 @@ for spec in "$@"; do
   rc=$?
   echo "   rc=$rc" | tee -a gpurun_out/seq.log
   tail -n 3 "gpurun_out/$log"
-  if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then echo "step killed at its limit: stopping" | tee -a gpurun_out/seq.log; exit 1; fi
+  if [ $rc -eq 124 ] || [ $rc -eq 137 ] || [ $rc -eq 134 ] || [ $rc -eq 139 ]; then echo "step killed at its limit or crashed (GPU fault): stopping" | tee -a gpurun_out/seq.log; exit 1; fi
 done
 exit 0
