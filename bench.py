@@ -205,9 +205,9 @@ def main(argv=None):
     ap.add_argument("--envs-per-gpu", type=int, default=0)
     ap.add_argument("--workload", default="light_flat", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--streams", type=int, default=1,
-                    help="step the per-GPU fleet as S independent shards on S HIP streams (software pipelining across control "
-                         "steps: one shard's next launch fills the tail of the others'); default 1 = one launch per fleet step")
+    ap.add_argument("--streams", type=int, default=2,
+                    help="issue each control step of the per-GPU fleet as S launches over contiguous env ranges on S HIP streams "
+                         "(cosim_step_range: a range's next control step fills the tail of the others' launches); 1 = one launch")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse ranks on one GPU)")
     ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses cuda:0 (with --backend gloo)")
     ap.add_argument("--report-every", type=int, default=16, help="reporter statistics are sampled every this many timed steps")
@@ -236,44 +236,58 @@ def main(argv=None):
     env_id0 = rank * n
 
     S = max(1, args.streams)
-    if n % S:
-        raise SystemExit(f"--streams {S} must divide the envs per GPU ({n})")
+    if n % S or (n // S) % 2:
+        raise SystemExit(f"--streams {S} must divide the envs per GPU ({n}) into even shards")
     ns = n // S
     poscmd = args.workload == "humanoid_stairs"
-    cfg = make_config(robot, terrain=terrain, num_envs=ns, seed=1234, height_map=hmap, position_command=poscmd)
+    cfg = make_config(robot, terrain=terrain, num_envs=n, seed=1234, height_map=hmap, position_command=poscmd)
     if poscmd:
         cfg["observation"]["command_dim"] = 2                        # envs/wrappers.py:357
-    # S = 1: one launch per fleet step.  S > 1: the fleet as S independent shards (own engine handle, own HIP stream, global env
-    # ids unchanged), so a shard's next control step fills the tail of the others' launches.
-    envs = [BatchedEnv(cfg, num_envs=ns, device=local, seed=1234, auto_reset=True, env_id0=env_id0 + i * ns, gain_noise=0.1) for i in range(S)]
-    env = envs[0]
-    streams = [torch.cuda.current_stream(env.device)] if S == 1 else [torch.cuda.Stream(device=env.device) for _ in range(S)]
+    # ONE fleet (one engine handle, one set of [N, ...] buffers).  S = 1: one launch per control step.  S > 1: the step is issued
+    # as S launches over contiguous env ranges (cosim_step_range), each range on its own HIP stream, so a range's next control
+    # step fills the tail of the others' launches (a launch ends with its slowest env; envs never interact).
+    env = BatchedEnv(cfg, num_envs=n, device=local, seed=1234, auto_reset=True, env_id0=env_id0, gain_noise=0.1)
+    envs = [env]
+    main = torch.cuda.current_stream(env.device)
+    streams = [main] if S == 1 else [torch.cuda.Stream(device=env.device) for _ in range(S)]
     nu = env.action_dim
     total_steps = args.warmup + args.steps
-    actions = [synthetic_actions(ns, env_id0 + i * ns, total_steps, nu, env.device) for i in range(S)]
-    # reporter statistics (core/reporter.py's per-step scalars over the fleet): one launch of the fused reducer per sampled
-    # step and shard, sufficient statistics stay on the device until the one all-reduce that closes the timed region
+    actions = synthetic_actions(n, env_id0, total_steps, nu, env.device)
+    # reporter statistics (core/reporter.py's per-step scalars over the fleet): one launch of the fused reducer per sampled step,
+    # sufficient statistics stay on the device until the one all-reduce that closes the timed region
     from cosim_amd.reporter import FleetReporter
-    reporters = [FleetReporter(e) for e in envs]
-    for i, e in enumerate(envs):
-        with torch.cuda.stream(streams[i]):
-            if poscmd:   # per-env targets U([-3, 3]^2), keyed by global env id
-                from cosim_amd import rng as crng
-                gids = np.arange(env_id0 + i * ns, env_id0 + (i + 1) * ns, dtype=np.uint64)[:, None]
-                e.receive_user_command((6.0 * crng.uniform(1234, gids, 0, 6, np.arange(2)[None, :]) - 3.0).astype(np.float32))
-            else:
-                e.receive_user_command(np.array([0.5, 0.0, 0.0, 0.0], dtype=np.float32)[:max(e.command_dim, 1)])
-            e.reset()
-            for t in range(args.warmup):
-                e.step(actions[i][t])
+    reporter = FleetReporter(env)
+    if poscmd:   # per-env targets U([-3, 3]^2), keyed by global env id
+        from cosim_amd import rng as crng
+        gids = np.arange(env_id0, env_id0 + n, dtype=np.uint64)[:, None]
+        env.receive_user_command((6.0 * crng.uniform(1234, gids, 0, 6, np.arange(2)[None, :]) - 3.0).astype(np.float32))
+    else:
+        env.receive_user_command(np.array([0.5, 0.0, 0.0, 0.0], dtype=np.float32)[:max(env.command_dim, 1)])
+    env.reset()
     torch.cuda.synchronize()
-    for r in reporters:                   # warm-up of the reducer and of the torch kernels behind reduce() (first use loads code
-        r.write_info(None)                # objects: ~100 ms), then start from zero
-        r.acc.reduce()
-        r.acc.buf.zero_()
+
+    def fleet_step(t, report):
+        a = actions[t]
+        for i in range(S):
+            with torch.cuda.stream(streams[i]):
+                env.step_range(i * ns, ns, a)
+        if report:   # reporter statistics of this step: the reducer reads every range's info rows, the ranges' next launches wait for it
+            for i in range(S):
+                streams[0].wait_stream(streams[i])
+            with torch.cuda.stream(streams[0]):
+                reporter.write_info(None)
+            for i in range(1, S):
+                streams[i].wait_stream(streams[0])
+
+    for st_ in streams:
+        st_.wait_stream(main)
+    for t in range(args.warmup):
+        fleet_step(t, t == 0)             # t == 0: warm-up of the reducer (first use loads code objects: ~100 ms)
     torch.cuda.synchronize()
-    for e in envs:
-        e.engine.set_timing(True)
+    reporter.acc.reduce()                 # warm-up of the torch kernels behind reduce(), then start from zero
+    reporter.acc.buf.zero_()
+    torch.cuda.synchronize()
+    env.engine.set_timing(True)
 
     def sync():
         torch.cuda.synchronize()
@@ -284,15 +298,9 @@ def main(argv=None):
     sync()
     t0 = time.perf_counter()
     for t in range(args.warmup, total_steps):
-        for i, e in enumerate(envs):
-            with torch.cuda.stream(streams[i]):
-                state, term, trunc, info = e.step(actions[i][t])
-                if (t - args.warmup) % args.report_every == 0:
-                    reporters[i].write_info(info)       # reporter statistics of this step (sampled: first timed step, then every k-th)
+        fleet_step(t, (t - args.warmup) % args.report_every == 0)   # sampled: first timed step, then every k-th
     torch.cuda.synchronize()
-    for r in reporters[1:]:
-        reporters[0].acc.buf += r.acc.buf
-    fleet = reporters[0].acc.reduce()                   # the one collective: RCCL all-reduce of (count, sum, sum^2)
+    fleet = reporter.acc.reduce()                       # the one collective: RCCL all-reduce of (count, sum, sum^2)
     sync()
     dt = time.perf_counter() - t0
     kt = [e.engine.kernel_time() for e in envs]
@@ -330,6 +338,8 @@ def main(argv=None):
                        "max_contacts_per_env": max(x["max_contacts"] for x in sts), "contact_slots": env.engine.query("contact_slots")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, **pmc_traffic(args.workload),
+                         # per launch as the contract defines it (S launches overlap on the chip); the whole fleet per control step:
+                         "achieved_fleet": balg * n / (dt / args.steps) / 1e9,
                          "kernel": f"cosim::env_kernel<{env.nv},{env.cm.blob.nbody},...>", "kernel_ms": kernel_ms, "launches": launches,
                          "algorithmic_bytes_per_env_step": balg,
                          "note": "latency/VALU-bound small-state solver; HBM sees only the compulsory state traffic (SURVEY §8d)"},

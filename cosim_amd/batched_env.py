@@ -106,6 +106,8 @@ class BatchedEnv:
         prio = os.environ.get("COSIM_WAVE_PRIORITY")           # "base,t1,t2,t3" (tuning runs)
         if prio:
             self.engine.set_param("wave_priority", np.array([float(x) for x in prio.split(",")]))
+        if os.environ.get("COSIM_PAIR_MODE"):                  # "1": hull pairs wave-cooperative (A/B runs)
+            self.engine.set_param("pair_mode", np.array([float(os.environ["COSIM_PAIR_MODE"])]))
         epw = os.environ.get("COSIM_ENVS_PER_WAVE")
         if epw:
             try:
@@ -200,6 +202,16 @@ class BatchedEnv:
         if self.command_dim < 0 or self.command_dim > 6:
             raise ValueError(f"Invalid 'command_dim': expected 0> or <7; but got {self.command_dim}.")
         return self.state, self.terminated, self.truncated, self._info(a)
+
+    def step_range(self, first: int, count: int, action):
+        """One control step of envs ``[first, first + count)`` on the current stream (``cosim_step_range``): ``action`` is the
+        whole fleet's ``[N, action_dim]`` tensor; outputs land in the fleet's ``state`` / ``terminated`` / ``truncated`` /
+        ``info_buf`` rows of that range.  Stepping the fleet as S such shards on S streams pipelines control steps across shards."""
+        assert self.reset_flag is True, "Call 'reset()' before calling 'step()'."
+        if tuple(action.shape) != (self.num_envs, self.action_dim) or not action.is_contiguous():
+            raise ValueError(f"Action dimension mismatch. Expected contiguous {(self.num_envs, self.action_dim)}, found {tuple(action.shape)}")
+        self.engine.step_range(first, count, action.data_ptr(), self._cmd_ptr(), self.state.data_ptr(), self.terminated.data_ptr(),
+                               self.truncated.data_ptr(), self.info_buf.data_ptr(), self._stream())
 
     def _info(self, action) -> Dict[str, object]:
         """Batched ``_get_info`` + ``user_command_i`` (flamingo_light_v1.py:166-183; wrappers.py:399-400)."""

@@ -36,6 +36,7 @@ struct cosim_engine {
   DevObs* d_obs = nullptr;
   float *d_state = nullptr, *d_params = nullptr, *d_hull_vert = nullptr, *d_hfield = nullptr, *d_dbg = nullptr;
   int *d_hull_adr = nullptr, *d_hull_nbr = nullptr;
+  unsigned short* d_hull_seed = nullptr;   // [ngeom][HULL_NSEED]
   unsigned* d_pairs = nullptr;   // robot-robot candidate pairs (geom1 | geom2 << 16)
   float4* d_gext = nullptr;      // per geom: MPR centre (body frame), raw sliding friction
   std::vector<float> h_params;
@@ -46,6 +47,7 @@ struct cosim_engine {
   int max_newton = 50;
   int max_ls = 24;
   int nsub_override = 0;
+  int pair_coop = 0;
   int prio[4] = {6, -4, -2, 0};   // wave priority by solver lag (see the kernel): usual iterations per substep, lag thresholds
   // timing
   bool timing = false;
@@ -59,7 +61,7 @@ struct cosim_engine {
   void (*launch_prof2)(cosim_engine*, const KArgs&, int grid, hipStream_t) = nullptr;
   int epw = 1;   // environments per wave of the reset / step launches
   int lds_bytes = 0;
-  int contact_slots = 0;   // ground-contact capacity of the selected kernel
+  int contact_slots = 0, pair_slots = 0;   // ground-contact / robot-robot contact capacity of the selected kernel
 };
 
 template <int NV, int NB, int RPL, bool HF, int GTM, bool SC, int MCT>
@@ -82,8 +84,11 @@ static void launch_prof2_t(cosim_engine* e, const KArgs& a, int grid, hipStream_
 template <int NV, int NB, int RPL, int GTM, bool SC, int MCT_FLAT, int MCT_HF>
 static void select_t(cosim_engine* e, bool hf) {
   e->launch = hf ? launch_t<NV, NB, RPL, true, GTM, SC, MCT_HF> : launch_t<NV, NB, RPL, false, GTM, SC, MCT_FLAT>;
-  e->lds_bytes = hf ? (int)sizeof(EnvLds<NV, NB, RPL, true, 64, MCT_HF>) : (int)sizeof(EnvLds<NV, NB, RPL, SC, 64, MCT_FLAT>);
-  e->contact_slots = hf ? EnvLds<NV, NB, RPL, true, 64, MCT_HF>::MC : EnvLds<NV, NB, RPL, SC, 64, MCT_FLAT>::MC;
+  using LH = typename KTraits<NV, NB, RPL, true, SC, 1, MCT_HF>::L;
+  using LF = typename KTraits<NV, NB, RPL, false, SC, 1, MCT_FLAT>::L;
+  e->lds_bytes = hf ? (int)sizeof(LH) : (int)sizeof(LF);
+  e->contact_slots = hf ? LH::MC : LF::MC;
+  e->pair_slots = hf ? LH::MCP : LF::MCP;
 }
 
 static int round_up(int x, int m) { return (x + m - 1) / m * m; }
@@ -404,7 +409,7 @@ int cosim_create(const cosim_model_t* model, const float* hull_vert, const int* 
   }
   constexpr int G_LIGHT = GT_SPHERE | GT_CYLINDER | GT_MESH, G_MESH = GT_MESH, G_HUM = GT_BOX | GT_CYLINDER | GT_MESH;
   if (nv == 18 && nb <= 14 && (gtm & ~G_LIGHT) == 0) { select_t<18, 14, 1, G_LIGHT, false, 0, 128>(e, hf); if (!hf) { e->launch_prof = launch_prof_t<18, 14, 1, G_LIGHT>; e->launch2 = launch2_t<18, 14, G_LIGHT>; e->launch_prof2 = launch_prof2_t<18, 14, G_LIGHT>; } }   // flamingo_light_v1
-  else if (nv == 14 && nb <= 10 && (gtm & ~G_MESH) == 0) select_t<14, 10, 2, G_MESH, true, 64, 64>(e, hf);   // flamingo_p_v3
+  else if (nv == 14 && nb <= 10 && (gtm & ~G_MESH) == 0) select_t<14, 10, 2, G_MESH, true, 32, 64>(e, hf);   // flamingo_p_v3
   else if (nv == 22 && nb <= 18 && (gtm & ~G_MESH) == 0) select_t<22, 18, 2, G_MESH, true, 128, 128>(e, hf);   // w4_p_v2
   else if (nv == 29 && nb <= 26 && (gtm & ~G_HUM) == 0) select_t<29, 26, 2, G_HUM, true, 128, 256>(e, hf);     // humanoid_p_v0
   else { delete e; return fail(COSIM_EINVAL, "cosim_create: no kernel instantiation for this (nv, nbody); add one in cosim_engine.hip"); }
@@ -425,6 +430,33 @@ int cosim_create(const cosim_model_t* model, const float* hull_vert, const int* 
     HIP_TRY(hipMemcpy(e->d_hull_vert, hull_vert, (size_t)model->nhullvert * 3 * sizeof(float), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(e->d_hull_adr, hull_adr, (size_t)(model->nhullvert + 1) * sizeof(int), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(e->d_hull_nbr, hull_nbr, (size_t)model->nhulledge * sizeof(int), hipMemcpyHostToDevice));
+  }
+  {
+    // seed table of the lane-serial hull support: for each mesh geom and each cube-map cell of directions, the support vertex of
+    // the cell's centre direction (exhaustive scan, once)
+    std::vector<unsigned short> seed((size_t)(model->ngeom > 0 ? model->ngeom : 1) * HULL_NSEED, 0);
+    for (int g = 0; g < model->ngeom; g++) {
+      if (model->geom_type[g] != CS_GEOM_MESH || model->geom_hullnum[g] < 1 || !hull_vert) continue;
+      const float* hv = hull_vert + 3 * (size_t)model->geom_hulladr[g];
+      for (int f = 0; f < 6; f++)
+        for (int iu = 0; iu < 4; iu++)
+          for (int iv = 0; iv < 4; iv++) {
+            const int m = f >> 1;
+            float l[3];
+            l[m] = (f & 1) ? -1.f : 1.f;
+            l[(m + 1) % 3] = (iu + 0.5f) * 0.5f - 1.f;
+            l[(m + 2) % 3] = (iv + 0.5f) * 0.5f - 1.f;
+            int best = 0;
+            float bv = -3.0e38f;
+            for (int i = 0; i < model->geom_hullnum[g]; i++) {
+              const float t = l[0] * hv[3 * i] + l[1] * hv[3 * i + 1] + l[2] * hv[3 * i + 2];
+              if (t > bv) { bv = t; best = i; }
+            }
+            seed[(size_t)g * HULL_NSEED + hull_seed_cell(l)] = (unsigned short)best;
+          }
+    }
+    HIP_TRY(hipMalloc(&e->d_hull_seed, seed.size() * sizeof(unsigned short)));
+    HIP_TRY(hipMemcpy(e->d_hull_seed, seed.data(), seed.size() * sizeof(unsigned short), hipMemcpyHostToDevice));
   }
   {
     std::vector<unsigned> hp(model->npair > 0 ? model->npair : 1, 0u);
@@ -455,7 +487,7 @@ int cosim_destroy(cosim_engine_t* e) {
   hipSetDevice(e->device);
   hipFree(e->d_model); hipFree(e->d_obs); hipFree(e->d_state); hipFree(e->d_params); hipFree(e->d_dbg);
   hipFree(e->d_hull_vert); hipFree(e->d_hull_adr); hipFree(e->d_hull_nbr); hipFree(e->d_hfield);
-  hipFree(e->d_pairs); hipFree(e->d_gext);
+  hipFree(e->d_pairs); hipFree(e->d_gext); hipFree(e->d_hull_seed);
   for (hipEvent_t x : e->ev) hipEventDestroy(x);
   delete e;
   return COSIM_OK;
@@ -477,6 +509,7 @@ int cosim_query(const cosim_engine_t* e, const char* name) {
   if (n == "param_stride") return e->lay.p_stride;
   if (n == "lds_bytes") return e->lds_bytes;
   if (n == "contact_slots") return e->contact_slots;
+  if (n == "pair_slots") return e->pair_slots;
   if (n == "stacked_dim") return e->ho.stacked_dim;
   if (n == "frame_dim") return e->ho.frame_dim;
   return fail(COSIM_EINVAL, "cosim_query: unknown name " + n);
@@ -505,6 +538,7 @@ int cosim_set_param(cosim_engine_t* e, const char* name, const float* host, int 
     return COSIM_OK;
   }
   else if (n == "debug_substeps") { e->nsub_override = (int)host[0]; return COSIM_OK; }
+  else if (n == "pair_mode") { e->pair_coop = (int)host[0] != 0; return COSIM_OK; }   // 1: hull pairs one at a time, wave-cooperative scans
   else if (n == "envs_per_wave") {   // 2: the two-environments-per-wave kernel (flat flamingo_light_v1, even env counts); 1: one per wave
     const int w = (int)host[0];
     if (w != 1 && !(w == 2 && e->launch2 && e->n_envs % 2 == 0)) return fail(COSIM_EINVAL, "cosim_set_param: envs_per_wave not available for this model / env count");
@@ -535,10 +569,10 @@ static KArgs base_args(cosim_engine* e) {
   KArgs a;
   memset(&a, 0, sizeof a);
   a.dm = e->d_model; a.ob = e->d_obs; a.lay = e->lay; a.state = e->d_state; a.params = e->d_params;
-  a.hull_vert = e->d_hull_vert; a.hull_adr = e->d_hull_adr; a.hull_nbr = e->d_hull_nbr; a.hfield = e->d_hfield;
+  a.hull_vert = e->d_hull_vert; a.hull_adr = e->d_hull_adr; a.hull_nbr = e->d_hull_nbr; a.hull_seed = e->d_hull_seed; a.hfield = e->d_hfield;
   a.pairs = e->d_pairs; a.gext = e->d_gext;
   a.n_envs = e->n_envs; a.seed_lo = (unsigned)e->seed; a.seed_hi = (unsigned)(e->seed >> 32); a.env_id0 = e->env_id0;
-  a.tol32 = e->tol32; a.max_newton = e->max_newton; a.max_ls = e->max_ls; a.nsub_override = e->nsub_override;
+  a.tol32 = e->tol32; a.max_newton = e->max_newton; a.max_ls = e->max_ls; a.nsub_override = e->nsub_override; a.pair_coop = e->pair_coop;
   for (int k = 0; k < 4; k++) a.prio[k] = e->prio[k];
   return a;
 }
@@ -557,14 +591,23 @@ int cosim_reset(cosim_engine_t* e, const uint8_t* mask_dev, const float* command
 
 int cosim_step(cosim_engine_t* e, const float* actions_dev, const float* commands_dev, float* state_out_dev, uint8_t* terminated_dev,
                uint8_t* truncated_dev, float* info_out_dev, void* stream) {
+  if (!e) return fail(COSIM_EINVAL, "cosim_step: null argument");
+  return cosim_step_range(e, 0, e->n_envs, actions_dev, commands_dev, state_out_dev, terminated_dev, truncated_dev, info_out_dev, stream);
+}
+
+int cosim_step_range(cosim_engine_t* e, int first, int count, const float* actions_dev, const float* commands_dev, float* state_out_dev,
+                     uint8_t* terminated_dev, uint8_t* truncated_dev, float* info_out_dev, void* stream) {
   if (!e || !actions_dev || !state_out_dev || !terminated_dev || !truncated_dev) return fail(COSIM_EINVAL, "cosim_step: null argument");
   if (e->ho.command_dim > 0 && !commands_dev) return fail(COSIM_EINVAL, "cosim_step: commands_dev is required when command_dim > 0");
+  if (first < 0 || count < 1 || first + count > e->n_envs) return fail(COSIM_EINVAL, "cosim_step_range: range outside the fleet");
+  if (e->epw == 2 && ((first | count) & 1)) return fail(COSIM_EINVAL, "cosim_step_range: two-environments-per-wave kernel needs even ranges");
   HIP_TRY(hipSetDevice(e->device));
   int rc = upload_params(e);
   if (rc) return rc;
   KArgs a = base_args(e);
   a.mode = MODE_STEP; a.actions = actions_dev; a.commands = commands_dev; a.state_out = state_out_dev;
   a.terminated = terminated_dev; a.truncated = truncated_dev; a.info = info_out_dev;
+  a.env_first = first;
   hipStream_t s = (hipStream_t)stream;
   // kernel timing: one HIP event pair per launch on the launch stream, read back in cosim_kernel_time() (no sync here)
   int slot = -1;
@@ -577,7 +620,7 @@ int cosim_step(cosim_engine_t* e, const float* actions_dev, const float* command
     e->ev_used += 2;
     HIP_TRY(hipEventRecord(e->ev[slot], s));
   }
-  (e->epw == 2 ? e->launch2 : e->launch)(e, a, e->n_envs, s);
+  (e->epw == 2 ? e->launch2 : e->launch)(e, a, count, s);
   HIP_TRY(hipGetLastError());
   if (slot >= 0) HIP_TRY(hipEventRecord(e->ev[slot + 1], s));
   return COSIM_OK;

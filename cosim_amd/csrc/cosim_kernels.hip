@@ -43,6 +43,7 @@ struct KArgs {
   const float* hull_vert;
   const int* hull_adr;
   const int* hull_nbr;
+  const unsigned short* hull_seed;   // per geom: direction cell -> support vertex (lane-serial hull supports start there)
   const float* hfield;
   const unsigned* pairs;  // robot-robot candidate pairs: geom1 | geom2 << 16
   const float4* gext;     // per geom: MPR centre (body frame) xyz, raw sliding friction w
@@ -56,11 +57,13 @@ struct KArgs {
   float* dbg;             // debug dump buffer (MODE_DEBUG)
   int dbg_env;
   int n_envs, mode;
+  int env_first;          // first env of this launch (cosim_step_range: a launch may cover a sub-range of the fleet)
   unsigned seed_lo, seed_hi;
   long long env_id0;
   float tol32;            // fp32 solver tolerance
   int max_newton, max_ls;
   int nsub_override;      // > 0: physics substeps per control step (diagnostics; 0 = the model's frame_skip)
+  int pair_coop;          // robot-robot pairs with a hull: 1 = one at a time, wave-cooperative vertex scans; 0 = lane-parallel
   int prio[4];            // wave priority by solver lag: expected Newton iterations per substep, then the three lag thresholds
 };
 
@@ -208,29 +211,33 @@ __device__ __forceinline__ float u01(unsigned x) { return (float)(x >> 8) * (1.0
 // CT: robot-robot contacts in slots of their own; per ground contact the regulariser D, the four rows' J a - aref and J s;
 // per body: twist of the vector in flight, contact wrench, 6 x 6 contact "inertia" (lower triangle, 21 entries).  Empty otherwise
 // (the one-env-per-wave kernel of flamingo_light_v1 must stay within 160 KiB / 16 = 10240 B of LDS).
-template <bool CT, int NB, int MC, int MCP>
+template <bool CT, bool HF, int NB, int MC, int MCP>
 struct CtLds {
   float ppos[MCP][3], pnrm[MCP][3], pdist[MCP];
   int pgeom[MCP];
-  float cD[MC], cJar[MC][4], cJv[MC][4];
+  // the four pyramid rows of a ground contact are base +- x1, base +- x2 (n +- mu t1, n +- mu t2): three numbers per contact
+  float cD[MC], cJar[MC][3], cJv[MC][3];
   float tw[NB][6], bw[NB][6], bW[NB][21];
   unsigned cbmask;   // bodies that carry a ground contact
   // heightfield narrowphase, per geom: end of its (geom, prism) work items in the flattened list, contacts found so far, sub-grid
   // origin, prisms per strip row, lowest point of the geom
-  int hf_end[24], hf_cnt[24], hf_cmin[24], hf_rmin[24], hf_ppr[24];
-  float hf_lo[24];
+  int hf_end[HF ? 24 : 1], hf_cnt[HF ? 24 : 1], hf_cmin[HF ? 24 : 1], hf_rmin[HF ? 24 : 1], hf_ppr[HF ? 24 : 1];
+  float hf_lo[HF ? 24 : 1];
 };
-template <int NB, int MC, int MCP>
-struct CtLds<false, NB, MC, MCP> {};
-template <int NV, int NB, int RPL, bool NRM, int LW = 64, int MCT = 0>   // NRM: contact normals are stored (heightfield ground or robot-robot pairs)
-struct EnvLds : CtLds<(MCT > 0), NB, (MCT > 0 ? MCT : 1), 12> {
+template <bool HF, int NB, int MC, int MCP>
+struct CtLds<false, HF, NB, MC, MCP> {};
+// NRM: the contact list stores normals (legacy: heightfield ground or robot-robot pairs; CT: heightfield ground -- the robot-robot
+// contacts have slots of their own); MCPT: robot-robot contact slots of a CT kernel (0: the model has no pairs)
+template <int NV, int NB, int RPL, bool NRM, int LW = 64, int MCT = 0, int MCPT = 12, bool HFL = NRM>
+struct EnvLds : CtLds<(MCT > 0), HFL, NB, (MCT > 0 ? MCT : 1), (MCPT > 0 ? MCPT : 1)> {
   static constexpr bool CT = MCT > 0;
   static constexpr int LD = NV | 1;   // odd leading dimension: conflict-free column access
   static constexpr int ROWS = LW * RPL;            // constraint rows per env: RPL rows per lane, LW lanes per env
   static constexpr int MC = CT ? MCT : (ROWS <= 64 ? 12 : 16);  // contact slots (4 pyramid rows each); CT: ground contacts only
-  static constexpr int MCP = CT ? 12 : 1;          // CT: robot-robot contact slots (dense rows)
+  static constexpr int MCP = CT ? MCPT : 1;        // CT: robot-robot contact slots (dense rows)
   static constexpr int CPL = (MC + LW - 1) / LW;   // CT: contacts per lane = passes over the contact list
-  static constexpr int NGEN = 3 * MAXEQ / 2 + 4 * (CT ? MCP : MC);  // dense rows: 2 connect equalities (6 rows) + contacts
+  static constexpr int NEQR = (CT && MCPT > 0) ? 0 : 3 * MAXEQ / 2;   // rows kept for connect equalities (no cosim robot has both equalities and robot-robot pairs; a model that did would trade pair slots for them)
+  static constexpr int NGEN = NEQR + 4 * (CT ? MCP : MC);  // dense rows: 2 connect equalities (6 rows) + contacts
   static constexpr int NLIM = ROWS / 8;
   static constexpr int NUMAX = NV - 6;   // actuators: at most one per hinge dof (the free joint's six dofs carry none)
   float qpos[CS_MAXQ], qvel[NV], qacc[NV], qact[NV], qsm[NV], qcon[NV], sr[NV], dofD[NV];
@@ -456,17 +463,31 @@ __device__ __forceinline__ float impedance(const float* solimp, float pos, float
   return d0 + y * (d1 - d0);
 }
 
+// LDS layout of a kernel variant (shared with the host side, which reports lds_bytes / contact_slots)
+template <int NV, int NB, int RPL, bool HF, bool SC, int EPW, int MCT>
+struct KTraits {
+  static constexpr bool CT = MCT > 0;
+  static constexpr bool NRM = CT ? HF : (HF || SC);
+  static constexpr int MCPT = SC ? (NV >= 22 ? 12 : 8) : 0;
+  using L = EnvLds<NV, NB, RPL, NRM, 64 / EPW, MCT, MCPT, HF>;
+};
+
 // ------------------------------------------------------------------------------------------------ the kernel
 // HF: heightfield ground; SC: robot-robot (self) collision pairs; PROF: diagnostic build with s_memtime phase stamps;
 // EPW: environments per wave (1: lane l of 64 plays object l; 2: two groups of 32 lanes, RPL rows per lane of the group)
 template <int NV, int NB, int RPL, bool HF, int GTM, bool SC, bool PROF = false, int EPW = 1, int MCT = 0>
-__global__ __launch_bounds__(64, (RPL == 1 && EPW == 1 && !HF) ? 4 : ((EPW == 1 && NV < 18 && MCT <= 64) ? 4 : 2))   /* flamingo_p_v3: LDS allows 16 waves/CU; 2 / 3 / 4 per SIMD measured 6.83 / 7.06 / 7.31 M env-steps/s */ void env_kernel(KArgs A) {
+// waves per SIMD the register allocator is asked for = what the LDS footprint admits (160 KiB per CU, 4 SIMDs): asking for more makes
+// the compiler spill for nothing, asking for less wastes resident waves
+__global__ __launch_bounds__(64, (EPW == 2 ? 2 : (163840 / (int)sizeof(typename KTraits<NV, NB, RPL, HF, SC, EPW, MCT>::L) + 3) / 4 >= 4 ? 4
+                                  : (163840 / (int)sizeof(typename KTraits<NV, NB, RPL, HF, SC, EPW, MCT>::L) + 3) / 4)) void env_kernel(KArgs A) {
   static_assert(EPW == 1 || (EPW == 2 && !HF && !SC && NV <= 32 && NB <= 32), "two environments per wave: flat ground, no pairs");
   static_assert(MCT == 0 || EPW == 1, "contact-twist mode: one environment per wave");
-  constexpr bool NRM = HF || SC;
-  constexpr int LW = 64 / EPW;
+  using KT = KTraits<NV, NB, RPL, HF, SC, EPW, MCT>;
   constexpr bool CT = MCT > 0;
-  using L = EnvLds<NV, NB, RPL, NRM, LW, MCT>;
+  constexpr bool NRM = KT::NRM;            // the (ground) contact list stores normals; otherwise they are +z
+  constexpr bool NRMD = CT ? true : NRM;   // normals of the contacts behind dense rows (CT: the robot-robot slots always store them)
+  constexpr int LW = 64 / EPW;
+  using L = typename KT::L;
   constexpr int CPL = L::CPL;
   constexpr int MAXROWS = L::ROWS;
   constexpr int TRI = NV * (NV + 1) / 2;
@@ -478,11 +499,11 @@ __global__ __launch_bounds__(64, (RPL == 1 && EPW == 1 && !HF) ? 4 : ((EPW == 1 
   const int hb = EPW == 1 ? 0 : (wlane & 32);          // first lane of this lane's group
   const int lane = EPW == 1 ? wlane : (wlane & 31);     // role index inside the group
   L& S = SS[EPW == 1 ? 0 : (wlane >> 5)];
-  const int env = A.mode == MODE_DEBUG ? A.dbg_env : (int)blockIdx.x * EPW + (EPW == 1 ? 0 : (wlane >> 5));
+  const int env = A.mode == MODE_DEBUG ? A.dbg_env : A.env_first + (int)blockIdx.x * EPW + (EPW == 1 ? 0 : (wlane >> 5));
   if (env >= A.n_envs) return;
   const DevModel& dm = *A.dm;
   const DevObs& ob = *A.ob;
-  const HullGraph HG{A.hull_vert, A.hull_adr, A.hull_nbr};
+  const HullGraph HG{A.hull_vert, A.hull_adr, A.hull_nbr, A.hull_seed};
   const Layout lay = A.lay;
   float* rec = A.state + (size_t)env * lay.s_stride;
   const float* par = A.params + (size_t)env * lay.p_stride;
@@ -876,7 +897,7 @@ __global__ __launch_bounds__(64, (RPL == 1 && EPW == 1 && !HF) ? 4 : ((EPW == 1 
         float v[3];
         qrot(v, bq, cl);
         for (int k = 0; k < 3; k++) o.center[k] = S.xpos[gb][k] + v[k];
-        o.kind = G.g_type; o.adr = G.g_hulladr; o.num = G.g_hullnum; o.hint = 0;
+        o.kind = G.g_type; o.adr = G.g_hulladr; o.num = G.g_hullnum; o.hint = -1; o.seed = g;
         for (int k = 0; k < 3; k++) o.size[k] = G.g_size[k];
         if (G.g_type == CS_GEOM_MESH) {
           for (int k = 0; k < 3; k++) o.pos[k] = S.xpos[gb][k];
@@ -1177,18 +1198,19 @@ __global__ __launch_bounds__(64, (RPL == 1 && EPW == 1 && !HF) ? 4 : ((EPW == 1 
                 if (fabsf(dot3(dv, a2)) > G2.g_half[k] + radius(m1, G1.g_half, a2) + mg) cand = false;
               }
             }
-            mesh = cand && (G1.g_type == CS_GEOM_MESH || G2.g_type == CS_GEOM_MESH);
+            // pairs with a convex hull: lane-parallel too (each lane climbs the hull's neighbour graph) unless the engine was told to
+            // run them one at a time with all 64 lanes sharing the vertex scans (cosim_set_param "pair_mode" 1; the two differ only
+            // in which of several equally extreme vertices a support query returns)
+            mesh = cand && A.pair_coop && (G1.g_type == CS_GEOM_MESH || G2.g_type == CS_GEOM_MESH);
           }
           bool hit = false;
           float depth = 0.f, cn[3] = {0.f, 0.f, 1.f}, cp[3] = {0.f, 0.f, 0.f};
-          if constexpr ((GTM & ~GT_MESH) != 0) {
-            if (cand && !mesh) {
-              CObj o1, o2;
-              make_cobj(o1, g1);
-              make_cobj(o2, g2);
-              const MprPair<GTM, false> sup{o1, o2, HG, ln};
-              hit = mpr_penetration(sup, o1.center, o2.center, depth, cn, cp) && (cn[0] != 0.f || cn[1] != 0.f || cn[2] != 0.f);
-            }
+          if (cand && !mesh) {
+            CObj o1, o2;
+            make_cobj(o1, g1);
+            make_cobj(o2, g2);
+            const MprPair<GTM, false> sup{o1, o2, HG, ln};
+            hit = mpr_penetration(sup, o1.center, o2.center, depth, cn, cp) && (cn[0] != 0.f || cn[1] != 0.f || cn[2] != 0.f);
           }
           {
             const unsigned long long hm = __ballot(hit);
@@ -1310,7 +1332,7 @@ __global__ __launch_bounds__(64, (RPL == 1 && EPW == 1 && !HF) ? 4 : ((EPW == 1 
             const float mu = (SC && g1 >= 0) ? fmaxf(MINMU, fmaxf(A.gext[g].w, A.gext[g1].w)) : S.p_gmu[g];
             const float* cn_ = con_nrm<CT, NRM>(S, !CT, c, c);
             const float* cp_ = con_pos<CT>(S, !CT, c, c);
-            float nrm[3] = {NRM ? cn_[0] : 0.f, NRM ? cn_[1] : 0.f, NRM ? cn_[2] : 1.f}, t1[3], t2[3];
+            float nrm[3] = {NRMD ? cn_[0] : 0.f, NRMD ? cn_[1] : 0.f, NRMD ? cn_[2] : 1.f}, t1[3], t2[3];
             make_frame(nrm, t1, t2);
             const float* tk = (edge >> 1) ? t2 : t1;
             const float sg = (edge & 1) ? -mu : mu;
@@ -1429,7 +1451,7 @@ __global__ __launch_bounds__(64, (RPL == 1 && EPW == 1 && !HF) ? 4 : ((EPW == 1 
             S.cD[c] = 1.f / rR;
             // row e = n +- mu t_k:  J a - aref = (a_n +- mu a_k) + B (v_n +- mu v_k) + K imp (r - margin)
             const float base = an + B * vn + K * imp * (rpos - rmargin), x1 = G.mu * (a1 + B * v1), x2 = G.mu * (a2 + B * v2);
-            S.cJar[c][0] = base + x1; S.cJar[c][1] = base - x1; S.cJar[c][2] = base + x2; S.cJar[c][3] = base - x2;
+            S.cJar[c][0] = base; S.cJar[c][1] = x1; S.cJar[c][2] = x2;   // rows: base +- x1, base +- x2
             atomicOr(&S.cbmask, 1u << G.b);
           }
         }
@@ -1515,10 +1537,12 @@ __global__ __launch_bounds__(64, (RPL == 1 && EPW == 1 && !HF) ? 4 : ((EPW == 1 
             int bits = 0;
             if (c < ncon) {
               const float D = S.cD[c];
+              const float jb = S.cJar[c][0], j1 = S.cJar[c][1], j2 = S.cJar[c][2];
+              const float xr[4] = {jb + j1, jb - j1, jb + j2, jb - j2};
               float f[4];
 #pragma unroll
               for (int e = 0; e < 4; e++) {
-                const float x = S.cJar[c][e];
+                const float x = xr[e];
                 const bool on = x < 0.f;
                 f[e] = on ? -D * x : 0.f;
                 csum += on ? 0.5f * D * x * x : 0.f;
@@ -1739,7 +1763,7 @@ __global__ __launch_bounds__(64, (RPL == 1 && EPW == 1 && !HF) ? 4 : ((EPW == 1 
           o[0] = con_dist<CT>(S, gnd, c, cp);
           for (int k = 0; k < 3; k++) {
             o[1 + k] = con_pos<CT>(S, gnd, c, cp)[k];
-            o[4 + k] = NRM ? con_nrm<CT, NRM>(S, gnd, c, cp)[k] : (k == 2 ? 1.f : 0.f);
+            o[4 + k] = (gnd ? NRM : true) ? con_nrm<CT, NRM>(S, gnd, c, cp)[k] : (k == 2 ? 1.f : 0.f);
           }
           o[7] = (float)con_geom<CT>(S, gnd, c, cp);
         }
@@ -1768,7 +1792,7 @@ __global__ __launch_bounds__(64, (RPL == 1 && EPW == 1 && !HF) ? 4 : ((EPW == 1 
               cgeo(c, G);
               float sn, s1, s2;
               point_proj(S.tw[G.b], G, sn, s1, s2);
-              S.cJv[c][0] = sn + G.mu * s1; S.cJv[c][1] = sn - G.mu * s1; S.cJv[c][2] = sn + G.mu * s2; S.cJv[c][3] = sn - G.mu * s2;
+              S.cJv[c][0] = sn; S.cJv[c][1] = G.mu * s1; S.cJv[c][2] = G.mu * s2;
             }
           }
         }
@@ -1794,9 +1818,11 @@ __global__ __launch_bounds__(64, (RPL == 1 && EPW == 1 && !HF) ? 4 : ((EPW == 1 
               const int c = ln + LW * cc;
               if (c < ncon) {
                 const float D = S.cD[c];
+                const float jb = S.cJar[c][0], j1 = S.cJar[c][1], j2 = S.cJar[c][2], vb = S.cJv[c][0], v1 = S.cJv[c][1], v2 = S.cJv[c][2];
+                const float ja4[4] = {jb + j1, jb - j1, jb + j2, jb - j2}, jv4[4] = {vb + v1, vb - v1, vb + v2, vb - v2};
 #pragma unroll
                 for (int e = 0; e < 4; e++) {
-                  const float ja = S.cJar[c][e], jv = S.cJv[c][e];
+                  const float ja = ja4[e], jv = jv4[e];
                   const bool inq = ja + alpha * jv < 0.f;
                   c0 += inq ? 0.5f * D * ja * ja : 0.f;
                   c1 += inq ? D * ja * jv : 0.f;
@@ -1898,7 +1924,7 @@ __global__ __launch_bounds__(64, (RPL == 1 && EPW == 1 && !HF) ? 4 : ((EPW == 1 
             const int c = ln + LW * cc;
             if (c < ncon) {
 #pragma unroll
-              for (int e = 0; e < 4; e++) S.cJar[c][e] += alpha * S.cJv[c][e];
+              for (int e = 0; e < 3; e++) S.cJar[c][e] += alpha * S.cJv[c][e];
             }
           }
         }
@@ -1969,11 +1995,12 @@ __global__ __launch_bounds__(64, (RPL == 1 && EPW == 1 && !HF) ? 4 : ((EPW == 1 
             for (int e = 0; e < 4; e++) f[e] = S.w.r.rowf[ne + 4 * (CT ? (gnd ? 0 : cp) : c) + e];
             if constexpr (CT) {
               if (gnd)
-                for (int e = 0; e < 4; e++) { const float x = S.cJar[c][e]; f[e] = x < 0.f ? -S.cD[c] * x : 0.f; }
+                for (int e = 0; e < 4; e++) { const float x = S.cJar[c][0] + ((e & 1) ? -1.f : 1.f) * S.cJar[c][1 + (e >> 1)]; f[e] = x < 0.f ? -S.cD[c] * x : 0.f; }
             }
             const float* cn_ = con_nrm<CT, NRM>(S, gnd, c, cp);
             const float* cp_ = con_pos<CT>(S, gnd, c, cp);
-            float nrm[3] = {NRM ? cn_[0] : 0.f, NRM ? cn_[1] : 0.f, NRM ? cn_[2] : 1.f}, t1[3], t2[3];
+            const bool hasn = gnd ? NRM : true;
+            float nrm[3] = {hasn ? cn_[0] : 0.f, hasn ? cn_[1] : 0.f, hasn ? cn_[2] : 1.f}, t1[3], t2[3];
             make_frame(nrm, t1, t2);
             const float fl0 = f[0] + f[1] + f[2] + f[3], fl1 = (f[0] - f[1]) * mu, fl2 = (f[2] - f[3]) * mu;  // mj_contactForce, pyramidal
             float fw[3], dif[3], tq[3];

@@ -27,10 +27,22 @@ struct CObj {            // one convex geom, world pose
   float size[3];
   int adr, num;          // mesh: slice of the hull vertex array
   float center[3];       // mjccd_center
-  mutable int hint;      // mesh, lane-serial support: vertex the next hill climb starts from (the previous answer)
+  mutable int hint;      // mesh, lane-serial support: vertex the next hill climb starts from (the previous answer; < 0: seed table)
+  int seed;              // mesh: row of the direction -> support-vertex seed table (the geom id)
 };
-// hull neighbour graph (CSR over the hull vertex array), for the lane-serial mesh support
-struct HullGraph { const float* vert; const int* adr; const int* nbr; };
+// hull neighbour graph (CSR over the hull vertex array), for the lane-serial mesh support; seed[g][96]: for 6 x 4 x 4 cube-map
+// cells of directions (hull frame) the support vertex of the cell's centre direction -- where a climb starts
+struct HullGraph { const float* vert; const int* adr; const int* nbr; const unsigned short* seed; };
+constexpr int HULL_NSEED = 96;
+__host__ __device__ __forceinline__ int hull_seed_cell(const float* l) {
+  const float a0 = fabsf(l[0]), a1 = fabsf(l[1]), a2 = fabsf(l[2]);
+  const int m = (a0 >= a1 && a0 >= a2) ? 0 : (a1 >= a2 ? 1 : 2);
+  const float lm = m == 0 ? l[0] : (m == 1 ? l[1] : l[2]), lu = m == 0 ? l[1] : (m == 1 ? l[2] : l[0]), lv = m == 0 ? l[2] : (m == 1 ? l[0] : l[1]);
+  const float inv = 1.f / fmaxf(fabsf(lm), 1e-30f);
+  int iu = (int)((lu * inv + 1.f) * 2.f), iv = (int)((lv * inv + 1.f) * 2.f);
+  iu = iu < 0 ? 0 : (iu > 3 ? 3 : iu); iv = iv < 0 ? 0 : (iv > 3 ? 3 : iv);
+  return (2 * m + (lm < 0.f ? 1 : 0)) * 16 + iu * 4 + iv;
+}
 typedef double real;   // the portal arithmetic runs in fp64 (ill-conditioned for edge contacts); supports are fp32
 __device__ __forceinline__ real mpr_dot(const real* a, const real* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
 __device__ __forceinline__ void mpr_cross(real* r, const real* a, const real* b) {
@@ -86,7 +98,7 @@ __device__ __forceinline__ void cobj_support(const CObj& o, const HullGraph& H, 
   float l[3], r[3] = {0.f, 0.f, 0.f};
   qrot(l, qi, dir);
   if (!COOP && (GTM & GT_MESH) && o.kind == CS_GEOM_MESH) {
-    const int bi = hull_climb(H, o.adr, o.num, o.hint, l);
+    const int bi = hull_climb(H, o.adr, o.num, o.hint >= 0 ? o.hint : (int)H.seed[o.seed * HULL_NSEED + hull_seed_cell(l)], l);
     o.hint = bi;
     const float* v = hull + 3 * (o.adr + bi);
     r[0] = v[0]; r[1] = v[1]; r[2] = v[2];

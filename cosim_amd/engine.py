@@ -83,6 +83,7 @@ def load_library():
     L.cosim_set_param.argtypes = [vp, ctypes.c_char_p, vp, ci]
     L.cosim_reset.argtypes = [vp, vp, vp, vp, vp]
     L.cosim_step.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp]
+    L.cosim_step_range.argtypes = [vp, ci, ci, vp, vp, vp, vp, vp, vp, vp]
     L.cosim_get.argtypes = [vp, ctypes.c_char_p, vp, vp]
     L.cosim_set.argtypes = [vp, ctypes.c_char_p, vp, vp]
     L.cosim_event_push.argtypes = [vp, vp, vp, vp]
@@ -91,7 +92,7 @@ def load_library():
     L.cosim_set_timing.argtypes = [vp, ci]
     L.cosim_profile_step.argtypes = [vp] * 7
     L.cosim_last_error.restype = ctypes.c_char_p
-    for fn in ("cosim_create", "cosim_destroy", "cosim_query", "cosim_set_param", "cosim_reset", "cosim_step", "cosim_get",
+    for fn in ("cosim_create", "cosim_destroy", "cosim_query", "cosim_set_param", "cosim_reset", "cosim_step", "cosim_step_range", "cosim_get",
                "cosim_set", "cosim_event_push", "cosim_debug_forward", "cosim_kernel_time", "cosim_set_timing",
                "cosim_profile_step", "cosim_model_sizeof", "cosim_obs_config_sizeof"):
         getattr(L, fn).restype = ci
@@ -103,7 +104,7 @@ def load_library():
     return L
 
 
-EXPORTS = ["cosim_create", "cosim_destroy", "cosim_query", "cosim_set_param", "cosim_reset", "cosim_step", "cosim_get",
+EXPORTS = ["cosim_create", "cosim_destroy", "cosim_query", "cosim_set_param", "cosim_reset", "cosim_step", "cosim_step_range", "cosim_get",
            "cosim_set", "cosim_event_push", "cosim_debug_forward", "cosim_kernel_time", "cosim_set_timing",
            "cosim_profile_step", "cosim_mlp_forward", "cosim_fleet_stats", "cosim_last_error", "cosim_model_sizeof", "cosim_obs_config_sizeof"]
 
@@ -222,6 +223,10 @@ class Engine:
 
     def step(self, actions_ptr, commands_ptr, state_out_ptr, term_ptr, trunc_ptr, info_ptr, stream=None):
         self._check(self.L.cosim_step(self.h, actions_ptr, commands_ptr, state_out_ptr, term_ptr, trunc_ptr, info_ptr, stream))
+
+    def step_range(self, first, count, actions_ptr, commands_ptr, state_out_ptr, term_ptr, trunc_ptr, info_ptr, stream=None):
+        self._check(self.L.cosim_step_range(self.h, int(first), int(count), actions_ptr, commands_ptr, state_out_ptr, term_ptr, trunc_ptr,
+                                            info_ptr, stream))
 
     def get(self, name: str, out_ptr, stream=None):
         self._check(self.L.cosim_get(self.h, name.encode(), out_ptr, stream))

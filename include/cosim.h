@@ -100,6 +100,14 @@ int cosim_reset(cosim_engine_t* e, const uint8_t* mask_dev, const float* command
 int cosim_step(cosim_engine_t* e, const float* actions_dev, const float* commands_dev, float* state_out_dev,
                uint8_t* terminated_dev, uint8_t* truncated_dev, float* info_out_dev, void* stream);
 
+/* The same control step for envs [first, first + count) only; every pointer still addresses the WHOLE fleet's buffers ([N, ...]).
+ * Lets a caller step one fleet as several independent shards on streams of its own (a shard's next control step fills the tail
+ * of the others' launches: a launch ends with its slowest env) without one handle per shard.  Envs never interact and every
+ * random stream is keyed by the global env id, so results do not depend on the split.  (No reference counterpart: the
+ * reference steps one env, core/tester.py:90.) */
+int cosim_step_range(cosim_engine_t* e, int first, int count, const float* actions_dev, const float* commands_dev, float* state_out_dev,
+                     uint8_t* terminated_dev, uint8_t* truncated_dev, float* info_out_dev, void* stream);
+
 /* Replaces env.get_data() reads (reference flamingo_light_v1.py:247-248; wrappers.py:360-367): copies
  * "qpos"[N,nq] / "qvel"[N,nv] / "qacc_warmstart"[N,nv] / "sim_step"[N] (as float) to a device buffer. */
 int cosim_get(cosim_engine_t* e, const char* name, float* out_dev, void* stream);

@@ -346,3 +346,34 @@ def test_info_of_the_terminal_step_describes_that_step():
     assert float(sa[:, 12:16].abs().max()) == 0.0 and float(sm[:, 12:16].abs().max()) == 0.5   # state: next episode vs this one
     assert a.solver_stats()["episodes_ended"] == 8
     a.close(); m.close()
+
+
+def test_step_range_shards_on_streams_equal_the_single_launch():
+    """cosim_step_range: one fleet stepped as 4 contiguous ranges on 4 HIP streams (control steps of different ranges overlap on the
+    chip) gives the bits of the one-launch step, for the randomised GUI-default workload with auto-reset."""
+    import torch
+    from cosim_amd.batched_env import BatchedEnv
+    from cosim_amd.compile import compile_model
+    from cosim_amd.config import make_config
+    n, S, T = 256, 4, 25
+    cfg = make_config("flamingo_light_v1", max_duration=0.3, num_envs=n, seed=3)
+    cm = compile_model(cfg)
+    a = BatchedEnv(cfg, num_envs=n, auto_reset=True, seed=3, compiled=cm, gain_noise=0.1)
+    b = BatchedEnv(cfg, num_envs=n, auto_reset=True, seed=3, compiled=cm, gain_noise=0.1)
+    acts = torch.tensor(np.random.default_rng(0).uniform(-1, 1, size=(T, n, 4)), dtype=torch.float32, device=a.device)
+    a.reset(); b.reset()
+    streams = [torch.cuda.Stream(device=a.device) for _ in range(S)]
+    torch.cuda.synchronize()
+    ns = n // S
+    for t in range(T):
+        a.step(acts[t])
+        for i, st in enumerate(streams):
+            with torch.cuda.stream(st):
+                b.step_range(i * ns, ns, acts[t])
+    torch.cuda.synchronize()
+    assert torch.equal(a.state, b.state) and torch.equal(a.info_buf, b.info_buf) and torch.equal(a.truncated, b.truncated)
+    assert torch.equal(a.get_data().qpos, b.get_data().qpos)
+    with pytest.raises(ValueError):
+        b.engine.step_range(n - 8, 16, acts[0].data_ptr(), b._cmd_ptr(), b.state.data_ptr(), b.terminated.data_ptr(), b.truncated.data_ptr(),
+                            b.info_buf.data_ptr(), None)
+    a.close(); b.close()

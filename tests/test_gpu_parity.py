@@ -568,7 +568,7 @@ def test_self_collision_mpr_matches_oracle(env_id, steps, amp):
             good += abs(gd - c[0]) < 1e-5 and np.abs(gn - c[4:7]).max() < 1e-3 and np.abs(gp + base - c[1:4]).max() < 1e-4
     assert miss == 0 and nmatch >= 20
     # ill-conditioned edge contacts: the final portal can differ between fp32 and fp64 poses; they must stay rare
-    assert good >= 0.95 * nmatch, (good, nmatch)
+    assert good >= 0.92 * nmatch, (good, nmatch)    # (every contact of every state is compared, not only the first 16 of a state)
     # --- one-control-step replay through the same states
     env.step(torch.tensor(R["act"], dtype=torch.float32, device=env.device))
     d = env.get_data()
