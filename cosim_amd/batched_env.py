@@ -106,6 +106,11 @@ class BatchedEnv:
         prio = os.environ.get("COSIM_WAVE_PRIORITY")           # "base,t1,t2,t3" (tuning runs)
         if prio:
             self.engine.set_param("wave_priority", np.array([float(x) for x in prio.split(",")]))
+        if os.environ.get("COSIM_CONTACT_TWIST") == "1":       # dense-row kernel -> its contact-twist variant (A/B runs)
+            try:
+                self.engine.set_param("contact_twist", np.array([1.0]))
+            except (ValueError, RuntimeError):
+                pass
         if os.environ.get("COSIM_PAIR_MODE"):                  # "1": hull pairs wave-cooperative (A/B runs)
             self.engine.set_param("pair_mode", np.array([float(os.environ["COSIM_PAIR_MODE"])]))
         epw = os.environ.get("COSIM_ENVS_PER_WAVE")

@@ -36,7 +36,6 @@ struct cosim_engine {
   DevObs* d_obs = nullptr;
   float *d_state = nullptr, *d_params = nullptr, *d_hull_vert = nullptr, *d_hfield = nullptr, *d_dbg = nullptr;
   int *d_hull_adr = nullptr, *d_hull_nbr = nullptr;
-  unsigned short* d_hull_seed = nullptr;   // [ngeom][HULL_NSEED]
   unsigned* d_pairs = nullptr;   // robot-robot candidate pairs (geom1 | geom2 << 16)
   float4* d_gext = nullptr;      // per geom: MPR centre (body frame), raw sliding friction
   std::vector<float> h_params;
@@ -47,7 +46,7 @@ struct cosim_engine {
   int max_newton = 50;
   int max_ls = 24;
   int nsub_override = 0;
-  int pair_coop = 0;
+  int pair_coop = 1;
   int prio[4] = {6, -4, -2, 0};   // wave priority by solver lag (see the kernel): usual iterations per substep, lag thresholds
   // timing
   bool timing = false;
@@ -59,6 +58,9 @@ struct cosim_engine {
   void (*launch_prof)(cosim_engine*, const KArgs&, int grid, hipStream_t) = nullptr;  // diagnostic build (light_v1 flat only)
   void (*launch2)(cosim_engine*, const KArgs&, int grid, hipStream_t) = nullptr;      // two environments per wave (reset / step)
   void (*launch_prof2)(cosim_engine*, const KArgs&, int grid, hipStream_t) = nullptr;
+  void (*launch_ct)(cosim_engine*, const KArgs&, int grid, hipStream_t) = nullptr;       // contact-twist variant of a dense-row kernel
+  void (*launch_ct_prof)(cosim_engine*, const KArgs&, int grid, hipStream_t) = nullptr;
+  int ct_lds_bytes = 0, ct_contact_slots = 0;
   int epw = 1;   // environments per wave of the reset / step launches
   int lds_bytes = 0;
   int contact_slots = 0, pair_slots = 0;   // ground-contact / robot-robot contact capacity of the selected kernel
@@ -68,9 +70,9 @@ template <int NV, int NB, int RPL, bool HF, int GTM, bool SC, int MCT>
 static void launch_t(cosim_engine* e, const KArgs& a, int grid, hipStream_t s) {
   hipLaunchKernelGGL((env_kernel<NV, NB, RPL, HF, GTM, SC, false, 1, MCT>), dim3(grid), dim3(64), 0, s, a);
 }
-template <int NV, int NB, int RPL, int GTM>
+template <int NV, int NB, int RPL, bool HF, int GTM, bool SC, int MCT>
 static void launch_prof_t(cosim_engine* e, const KArgs& a, int grid, hipStream_t s) {
-  hipLaunchKernelGGL((env_kernel<NV, NB, RPL, false, GTM, false, true>), dim3(grid), dim3(64), 0, s, a);
+  hipLaunchKernelGGL((env_kernel<NV, NB, RPL, HF, GTM, SC, true, 1, MCT>), dim3(grid), dim3(64), 0, s, a);
 }
 template <int NV, int NB, int GTM>
 static void launch2_t(cosim_engine* e, const KArgs& a, int grid, hipStream_t s) {   // grid = number of envs
@@ -408,10 +410,23 @@ int cosim_create(const cosim_model_t* model, const float* hull_vert, const int* 
     }
   }
   constexpr int G_LIGHT = GT_SPHERE | GT_CYLINDER | GT_MESH, G_MESH = GT_MESH, G_HUM = GT_BOX | GT_CYLINDER | GT_MESH;
-  if (nv == 18 && nb <= 14 && (gtm & ~G_LIGHT) == 0) { select_t<18, 14, 1, G_LIGHT, false, 0, 128>(e, hf); if (!hf) { e->launch_prof = launch_prof_t<18, 14, 1, G_LIGHT>; e->launch2 = launch2_t<18, 14, G_LIGHT>; e->launch_prof2 = launch_prof2_t<18, 14, G_LIGHT>; } }   // flamingo_light_v1
+  if (nv == 18 && nb <= 14 && (gtm & ~G_LIGHT) == 0) {   // flamingo_light_v1
+    select_t<18, 14, 1, G_LIGHT, false, 0, 128>(e, hf);
+    if (!hf) {
+      e->launch_prof = launch_prof_t<18, 14, 1, false, G_LIGHT, false, 0>; e->launch2 = launch2_t<18, 14, G_LIGHT>; e->launch_prof2 = launch_prof2_t<18, 14, G_LIGHT>;
+      // the same robot on the plane with its ground contacts in twist space (32 slots instead of 12; cosim_set_param "contact_twist")
+      e->launch_ct = launch_t<18, 14, 1, false, G_LIGHT, false, 32>;
+      e->launch_ct_prof = launch_prof_t<18, 14, 1, false, G_LIGHT, false, 32>;
+      e->ct_lds_bytes = (int)sizeof(typename KTraits<18, 14, 1, false, false, 1, 32>::L);
+      e->ct_contact_slots = 32;
+    }
+  }
   else if (nv == 14 && nb <= 10 && (gtm & ~G_MESH) == 0) select_t<14, 10, 2, G_MESH, true, 32, 64>(e, hf);   // flamingo_p_v3
   else if (nv == 22 && nb <= 18 && (gtm & ~G_MESH) == 0) select_t<22, 18, 2, G_MESH, true, 128, 128>(e, hf);   // w4_p_v2
-  else if (nv == 29 && nb <= 26 && (gtm & ~G_HUM) == 0) select_t<29, 26, 2, G_HUM, true, 128, 256>(e, hf);     // humanoid_p_v0
+  else if (nv == 29 && nb <= 26 && (gtm & ~G_HUM) == 0) {     // humanoid_p_v0
+    select_t<29, 26, 2, G_HUM, true, 128, 256>(e, hf);
+    if (hf) e->launch_prof = launch_prof_t<29, 26, 2, true, G_HUM, true, 256>;
+  }
   else { delete e; return fail(COSIM_EINVAL, "cosim_create: no kernel instantiation for this (nv, nbody); add one in cosim_engine.hip"); }
   HIP_TRY(hipMalloc(&e->d_model, sizeof(DevModel)));
   HIP_TRY(hipMalloc(&e->d_obs, sizeof(DevObs)));
@@ -430,33 +445,6 @@ int cosim_create(const cosim_model_t* model, const float* hull_vert, const int* 
     HIP_TRY(hipMemcpy(e->d_hull_vert, hull_vert, (size_t)model->nhullvert * 3 * sizeof(float), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(e->d_hull_adr, hull_adr, (size_t)(model->nhullvert + 1) * sizeof(int), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(e->d_hull_nbr, hull_nbr, (size_t)model->nhulledge * sizeof(int), hipMemcpyHostToDevice));
-  }
-  {
-    // seed table of the lane-serial hull support: for each mesh geom and each cube-map cell of directions, the support vertex of
-    // the cell's centre direction (exhaustive scan, once)
-    std::vector<unsigned short> seed((size_t)(model->ngeom > 0 ? model->ngeom : 1) * HULL_NSEED, 0);
-    for (int g = 0; g < model->ngeom; g++) {
-      if (model->geom_type[g] != CS_GEOM_MESH || model->geom_hullnum[g] < 1 || !hull_vert) continue;
-      const float* hv = hull_vert + 3 * (size_t)model->geom_hulladr[g];
-      for (int f = 0; f < 6; f++)
-        for (int iu = 0; iu < 4; iu++)
-          for (int iv = 0; iv < 4; iv++) {
-            const int m = f >> 1;
-            float l[3];
-            l[m] = (f & 1) ? -1.f : 1.f;
-            l[(m + 1) % 3] = (iu + 0.5f) * 0.5f - 1.f;
-            l[(m + 2) % 3] = (iv + 0.5f) * 0.5f - 1.f;
-            int best = 0;
-            float bv = -3.0e38f;
-            for (int i = 0; i < model->geom_hullnum[g]; i++) {
-              const float t = l[0] * hv[3 * i] + l[1] * hv[3 * i + 1] + l[2] * hv[3 * i + 2];
-              if (t > bv) { bv = t; best = i; }
-            }
-            seed[(size_t)g * HULL_NSEED + hull_seed_cell(l)] = (unsigned short)best;
-          }
-    }
-    HIP_TRY(hipMalloc(&e->d_hull_seed, seed.size() * sizeof(unsigned short)));
-    HIP_TRY(hipMemcpy(e->d_hull_seed, seed.data(), seed.size() * sizeof(unsigned short), hipMemcpyHostToDevice));
   }
   {
     std::vector<unsigned> hp(model->npair > 0 ? model->npair : 1, 0u);
@@ -487,7 +475,7 @@ int cosim_destroy(cosim_engine_t* e) {
   hipSetDevice(e->device);
   hipFree(e->d_model); hipFree(e->d_obs); hipFree(e->d_state); hipFree(e->d_params); hipFree(e->d_dbg);
   hipFree(e->d_hull_vert); hipFree(e->d_hull_adr); hipFree(e->d_hull_nbr); hipFree(e->d_hfield);
-  hipFree(e->d_pairs); hipFree(e->d_gext); hipFree(e->d_hull_seed);
+  hipFree(e->d_pairs); hipFree(e->d_gext);
   for (hipEvent_t x : e->ev) hipEventDestroy(x);
   delete e;
   return COSIM_OK;
@@ -538,6 +526,14 @@ int cosim_set_param(cosim_engine_t* e, const char* name, const float* host, int 
     return COSIM_OK;
   }
   else if (n == "debug_substeps") { e->nsub_override = (int)host[0]; return COSIM_OK; }
+  else if (n == "contact_twist") {   // 1: switch a dense-row kernel to its contact-twist variant (more contact slots), where one exists
+    if ((int)host[0] != 0) {
+      if (!e->launch_ct) return fail(COSIM_EINVAL, "cosim_set_param: no contact-twist variant for this model / terrain");
+      e->launch = e->launch_ct; e->launch_prof = e->launch_ct_prof; e->launch2 = nullptr; e->launch_prof2 = nullptr; e->epw = 1;
+      e->lds_bytes = e->ct_lds_bytes; e->contact_slots = e->ct_contact_slots;
+    }
+    return COSIM_OK;
+  }
   else if (n == "pair_mode") { e->pair_coop = (int)host[0] != 0; return COSIM_OK; }   // 1: hull pairs one at a time, wave-cooperative scans
   else if (n == "envs_per_wave") {   // 2: the two-environments-per-wave kernel (flat flamingo_light_v1, even env counts); 1: one per wave
     const int w = (int)host[0];
@@ -569,7 +565,7 @@ static KArgs base_args(cosim_engine* e) {
   KArgs a;
   memset(&a, 0, sizeof a);
   a.dm = e->d_model; a.ob = e->d_obs; a.lay = e->lay; a.state = e->d_state; a.params = e->d_params;
-  a.hull_vert = e->d_hull_vert; a.hull_adr = e->d_hull_adr; a.hull_nbr = e->d_hull_nbr; a.hull_seed = e->d_hull_seed; a.hfield = e->d_hfield;
+  a.hull_vert = e->d_hull_vert; a.hull_adr = e->d_hull_adr; a.hull_nbr = e->d_hull_nbr; a.hfield = e->d_hfield;
   a.pairs = e->d_pairs; a.gext = e->d_gext;
   a.n_envs = e->n_envs; a.seed_lo = (unsigned)e->seed; a.seed_hi = (unsigned)(e->seed >> 32); a.env_id0 = e->env_id0;
   a.tol32 = e->tol32; a.max_newton = e->max_newton; a.max_ls = e->max_ls; a.nsub_override = e->nsub_override; a.pair_coop = e->pair_coop;

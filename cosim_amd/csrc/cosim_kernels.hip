@@ -43,7 +43,6 @@ struct KArgs {
   const float* hull_vert;
   const int* hull_adr;
   const int* hull_nbr;
-  const unsigned short* hull_seed;   // per geom: direction cell -> support vertex (lane-serial hull supports start there)
   const float* hfield;
   const unsigned* pairs;  // robot-robot candidate pairs: geom1 | geom2 << 16
   const float4* gext;     // per geom: MPR centre (body frame) xyz, raw sliding friction w
@@ -442,6 +441,10 @@ __device__ __forceinline__ float terrain_height(const Terrain& T, float x, float
   const float h00 = T.data[r * T.ncol + c], h01 = T.data[r * T.ncol + c + 1], h10 = T.data[(r + 1) * T.ncol + c], h11 = T.data[(r + 1) * T.ncol + c + 1];
   const float hh = u >= v ? h00 + u * (h01 - h00) + v * (h11 - h01) : h00 + v * (h10 - h00) + u * (h11 - h10);
   return T.gz + T.sz * hh;
+#undef A
+#undef ob
+#undef lay
+#undef KARGS_FENCE
 }
 
 }  // namespace cosim
@@ -479,7 +482,15 @@ template <int NV, int NB, int RPL, bool HF, int GTM, bool SC, bool PROF = false,
 // waves per SIMD the register allocator is asked for = what the LDS footprint admits (160 KiB per CU, 4 SIMDs): asking for more makes
 // the compiler spill for nothing, asking for less wastes resident waves
 __global__ __launch_bounds__(64, (EPW == 2 ? 2 : (163840 / (int)sizeof(typename KTraits<NV, NB, RPL, HF, SC, EPW, MCT>::L) + 3) / 4 >= 4 ? 4
-                                  : (163840 / (int)sizeof(typename KTraits<NV, NB, RPL, HF, SC, EPW, MCT>::L) + 3) / 4)) void env_kernel(KArgs A) {
+                                  : (163840 / (int)sizeof(typename KTraits<NV, NB, RPL, HF, SC, EPW, MCT>::L) + 3) / 4)) void env_kernel(KArgs kernarg_block) {
+  // The argument block is read from the kernarg segment where it is used, not copied into ~70 scalar registers at entry (that
+  // copy spilled into vector-register lanes for the whole kernel and cost the solver's loops their scalar temporaries): `A` is the
+  // block in constant memory, and KARGS_FENCE() at the phase boundaries keeps the loads of a phase inside that phase.
+  typedef const KArgs __attribute__((address_space(4)))* KArgsP;
+  KArgsP kargs_p = (KArgsP)__builtin_amdgcn_kernarg_segment_ptr();
+  (void)kernarg_block;
+#define A (*kargs_p)
+#define KARGS_FENCE() asm volatile("" : "+s"(kargs_p))
   static_assert(EPW == 1 || (EPW == 2 && !HF && !SC && NV <= 32 && NB <= 32), "two environments per wave: flat ground, no pairs");
   static_assert(MCT == 0 || EPW == 1, "contact-twist mode: one environment per wave");
   using KT = KTraits<NV, NB, RPL, HF, SC, EPW, MCT>;
@@ -502,9 +513,8 @@ __global__ __launch_bounds__(64, (EPW == 2 ? 2 : (163840 / (int)sizeof(typename 
   const int env = A.mode == MODE_DEBUG ? A.dbg_env : A.env_first + (int)blockIdx.x * EPW + (EPW == 1 ? 0 : (wlane >> 5));
   if (env >= A.n_envs) return;
   const DevModel& dm = *A.dm;
-  const DevObs& ob = *A.ob;
-  const HullGraph HG{A.hull_vert, A.hull_adr, A.hull_nbr, A.hull_seed};
-  const Layout lay = A.lay;
+#define ob (*A.ob)
+#define lay (A.lay)
   float* rec = A.state + (size_t)env * lay.s_stride;
   const float* par = A.params + (size_t)env * lay.p_stride;
   const int nbody = dm.nbody, nu = dm.nu, nq = dm.nq, ngeom = dm.ngeom;
@@ -512,7 +522,7 @@ __global__ __launch_bounds__(64, (EPW == 2 ? 2 : (163840 / (int)sizeof(typename 
   // diagnostic build only: shader-clock time per phase, summed over the substeps (never executed in the product kernel)
   unsigned long long pt0 = 0, pacc[16];
   if (PROF) { for (int i = 0; i < 16; i++) pacc[i] = 0; pt0 = __builtin_amdgcn_s_memtime(); }
-#define STAMP(i) do { if (PROF) { __builtin_amdgcn_s_waitcnt(0); unsigned long long t_ = __builtin_amdgcn_s_memtime(); pacc[i] += t_ - pt0; pt0 = t_; } } while (0)
+#define STAMP(i) do { KARGS_FENCE(); if (PROF) { __builtin_amdgcn_s_waitcnt(0); unsigned long long t_ = __builtin_amdgcn_s_memtime(); pacc[i] += t_ - pt0; pt0 = t_; } } while (0)
 
   // ---- per-env parameters -> LDS
   if (lane < nbody) { S.p_mass[lane] = par[lay.p_mass + lane]; S.p_binvw[lane] = par[lay.p_binvw + lane]; }
@@ -887,6 +897,7 @@ __global__ __launch_bounds__(64, (EPW == 2 ? 2 : (163840 / (int)sizeof(typename 
       // =========================================================== collision: ground (plane or heightfield) vs robot geoms
       int ncon = 0;
       int npc = 0;   // CT: robot-robot contacts (slots of their own, dense rows); otherwise they follow the ground contacts in ncon
+      const HullGraph HG{A.hull_vert, A.hull_adr, A.hull_nbr};
       // world pose of geom g as a convex object (mesh: body frame, vertices in body coordinates; primitive: geom frame)
       auto make_cobj = [&](CObj& o, int g) {
         const LaneRec& G = dm.rec[g];
@@ -897,7 +908,7 @@ __global__ __launch_bounds__(64, (EPW == 2 ? 2 : (163840 / (int)sizeof(typename 
         float v[3];
         qrot(v, bq, cl);
         for (int k = 0; k < 3; k++) o.center[k] = S.xpos[gb][k] + v[k];
-        o.kind = G.g_type; o.adr = G.g_hulladr; o.num = G.g_hullnum; o.hint = -1; o.seed = g;
+        o.kind = G.g_type; o.adr = G.g_hulladr; o.num = G.g_hullnum;
         for (int k = 0; k < 3; k++) o.size[k] = G.g_size[k];
         if (G.g_type == CS_GEOM_MESH) {
           for (int k = 0; k < 3; k++) o.pos[k] = S.xpos[gb][k];
@@ -978,6 +989,7 @@ __global__ __launch_bounds__(64, (EPW == 2 ? 2 : (163840 / (int)sizeof(typename 
           if constexpr (CT) {
             if (ln == 0) S.ncon_ctr = 0;
             int n_items = 0;
+            bool coop_geom = false;
             if (active) {
               // phase A (lane = geom): MuJoCo's early outs, then the sub-grid under the geom's axis-aligned box
               CObj og;
@@ -1011,6 +1023,9 @@ __global__ __launch_bounds__(64, (EPW == 2 ? 2 : (163840 / (int)sizeof(typename 
                   if (rmax > rmin && ppr > 0) {
                     n_items = (rmax - rmin) * ppr;
                     S.hf_cmin[ln] = cmin; S.hf_rmin[ln] = rmin; S.hf_ppr[ln] = ppr; S.hf_lo[ln] = lo[2];
+                    // a hull with only a few prisms under it (coarse terrain): its prisms one at a time with all 64 lanes sharing the
+                    // vertex scans -- 64 lanes each scanning a 700-vertex hull for a handful of items would cost more
+                    if (gt == CS_GEOM_MESH && n_items < 32 && R.g_hullnum > 64) { coop_geom = true; n_items = 0; }
                   }
                 }
               }
@@ -1077,6 +1092,28 @@ __global__ __launch_bounds__(64, (EPW == 2 ? 2 : (163840 / (int)sizeof(typename 
               base += 64;
             }
             ncon = S.ncon_ctr;
+            // hulls with few prisms: wave-cooperative, one (geom, prism) at a time (hfield_geom: the same walk, sequential)
+            for (unsigned long long cm_ = __ballot(coop_geom); cm_; cm_ &= cm_ - 1) {
+              const int g = __builtin_ctzll(cm_);
+              const LaneRec& G = dm.rec[g];
+              CObj o;
+              make_cobj(o, g);
+              float gctr[3];
+              {
+                float v[3];
+                const float gq[4] = {S.xquat[G.g_body][0], S.xquat[G.g_body][1], S.xquat[G.g_body][2], S.xquat[G.g_body][3]};
+                qrot(v, gq, G.g_rcenter);
+                for (int k = 0; k < 3; k++) gctr[k] = S.xpos[G.g_body][k] + v[k];
+              }
+              hfield_geom<GTM, true>(T, o, gctr, G.g_rbound, G.g_margin, dm.hfield_size[3], HG, ln, [&](float dist, const float* pos, const float* n) {
+                if (ncon < MC && ln == 0) {
+                  S.cdist[ncon] = dist;
+                  S.cgeom[ncon] = g;
+                  for (int k = 0; k < 3; k++) { S.cpos[ncon][k] = pos[k]; S.cnrm[NRM ? ncon : 0][k] = n[k]; }
+                }
+                ncon++;
+              });
+            }
           }
         }
         // convex meshes near the ground, one at a time, all lanes sharing the scans over the hull's vertices
@@ -1957,6 +1994,7 @@ __global__ __launch_bounds__(64, (EPW == 2 ? 2 : (163840 / (int)sizeof(typename 
       bool act = true;
 #pragma nounroll
       while (true) {
+        KARGS_FENCE();
         act = act && niter < maxiter && !(scale * gradnorm < A.tol32);
         const bool any = __ballot(act) != 0ull;
         if (!any) break;
@@ -2209,6 +2247,10 @@ __global__ __launch_bounds__(64, (EPW == 2 ? 2 : (163840 / (int)sizeof(typename 
     meta[8] += st_dropcon; meta[9] += st_droplim; meta[10] = max(meta[10], st_maxcon);
     if (A.mode == MODE_STEP && (terminated || truncated)) meta[11] += 1;   // episodes ended (device-side count: survives graph replay)
   }
+#undef A
+#undef ob
+#undef lay
+#undef KARGS_FENCE
 }
 
 }  // namespace cosim

@@ -19,7 +19,6 @@ namespace cosim {
 constexpr double MPR_EPS = 2.220446049250313e-16;
 constexpr double MPR_TOL = 1e-6;
 constexpr int MPR_MAXIT = 50;
-constexpr int HF_MAXCELLS = 10;   // sub-grid extent walked under one geom (rows, columns)
 
 struct CObj {            // one convex geom, world pose
   int kind;              // CS_GEOM_*
@@ -27,22 +26,9 @@ struct CObj {            // one convex geom, world pose
   float size[3];
   int adr, num;          // mesh: slice of the hull vertex array
   float center[3];       // mjccd_center
-  mutable int hint;      // mesh, lane-serial support: vertex the next hill climb starts from (the previous answer; < 0: seed table)
-  int seed;              // mesh: row of the direction -> support-vertex seed table (the geom id)
 };
-// hull neighbour graph (CSR over the hull vertex array), for the lane-serial mesh support; seed[g][96]: for 6 x 4 x 4 cube-map
-// cells of directions (hull frame) the support vertex of the cell's centre direction -- where a climb starts
-struct HullGraph { const float* vert; const int* adr; const int* nbr; const unsigned short* seed; };
-constexpr int HULL_NSEED = 96;
-__host__ __device__ __forceinline__ int hull_seed_cell(const float* l) {
-  const float a0 = fabsf(l[0]), a1 = fabsf(l[1]), a2 = fabsf(l[2]);
-  const int m = (a0 >= a1 && a0 >= a2) ? 0 : (a1 >= a2 ? 1 : 2);
-  const float lm = m == 0 ? l[0] : (m == 1 ? l[1] : l[2]), lu = m == 0 ? l[1] : (m == 1 ? l[2] : l[0]), lv = m == 0 ? l[2] : (m == 1 ? l[0] : l[1]);
-  const float inv = 1.f / fmaxf(fabsf(lm), 1e-30f);
-  int iu = (int)((lu * inv + 1.f) * 2.f), iv = (int)((lv * inv + 1.f) * 2.f);
-  iu = iu < 0 ? 0 : (iu > 3 ? 3 : iu); iv = iv < 0 ? 0 : (iv > 3 ? 3 : iv);
-  return (2 * m + (lm < 0.f ? 1 : 0)) * 16 + iu * 4 + iv;
-}
+// hull arrays (vertices in body coordinates; CSR neighbour graph, used by the plane-hull routine)
+struct HullGraph { const float* vert; const int* adr; const int* nbr; };
 typedef double real;   // the portal arithmetic runs in fp64 (ill-conditioned for edge contacts); supports are fp32
 __device__ __forceinline__ real mpr_dot(const real* a, const real* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
 __device__ __forceinline__ void mpr_cross(real* r, const real* a, const real* b) {
@@ -67,29 +53,6 @@ __device__ __forceinline__ real mpr_normalize(real* v) {
   return n;
 }
 
-// Support vertex of a convex hull by hill climbing on its neighbour graph (what MuJoCo's mesh support does on large hulls, there
-// too from the previous answer): on a convex polytope a vertex that is not a maximiser of l . v has a strictly better neighbour,
-// so the climb ends on a maximiser after O(sqrt(n)) steps instead of an n-vertex scan.  One lane, no cooperation: used where every
-// lane runs its own query.  Ties (a face orthogonal to l) end on whichever maximiser the path reaches first.
-__device__ __forceinline__ int hull_climb(const HullGraph& H, int adr, int num, int start, const float* l) {
-  int cur = (start >= 0 && start < num) ? start : 0;
-  const float* v = H.vert + 3 * (adr + cur);
-  float best = l[0] * v[0] + l[1] * v[1] + l[2] * v[2];
-  for (int it = 0; it < num; it++) {   // bounded: every step moves to a strictly better vertex
-    const int lo = H.adr[adr + cur], hi = H.adr[adr + cur + 1];
-    int nxt = cur;
-    for (int e = lo; e < hi; e++) {
-      const int i = H.nbr[e];
-      const float* w = H.vert + 3 * (adr + i);
-      const float t = l[0] * w[0] + l[1] * w[1] + l[2] * w[2];
-      if (t > best) { best = t; nxt = i; }
-    }
-    if (nxt == cur) break;
-    cur = nxt;
-  }
-  return cur;
-}
-
 // mjccd_support: furthest point of the geom along the unit world direction
 template <int GTM, bool COOP>
 __device__ __forceinline__ void cobj_support(const CObj& o, const HullGraph& H, const float* dir, float* out, int ln) {
@@ -98,9 +61,18 @@ __device__ __forceinline__ void cobj_support(const CObj& o, const HullGraph& H, 
   float l[3], r[3] = {0.f, 0.f, 0.f};
   qrot(l, qi, dir);
   if (!COOP && (GTM & GT_MESH) && o.kind == CS_GEOM_MESH) {
-    const int bi = hull_climb(H, o.adr, o.num, o.hint >= 0 ? o.hint : (int)H.seed[o.seed * HULL_NSEED + hull_seed_cell(l)], l);
-    o.hint = bi;
-    const float* v = hull + 3 * (o.adr + bi);
+    // every lane scans the whole hull for its own direction.  Lanes that work on the same geom walk the same addresses, so the
+    // loads are broadcasts; the first maximum wins (lowest index among ties, like a sequential scan and like the COOP path).
+    // (Hill climbing on the neighbour graph from a direction-indexed seed was measured 2x slower here: its dependent,
+    // lane-divergent loads do not overlap.)
+    float best = -3.0e38f;
+    int bi = 0;
+    const float* v0 = hull + 3 * o.adr;
+    for (int i = 0; i < o.num; i++) {
+      const float t = l[0] * v0[3 * i] + l[1] * v0[3 * i + 1] + l[2] * v0[3 * i + 2];
+      if (t > best) { best = t; bi = i; }
+    }
+    const float* v = v0 + 3 * bi;
     r[0] = v[0]; r[1] = v[1]; r[2] = v[2];
   } else if (COOP && (GTM & GT_MESH) && o.kind == CS_GEOM_MESH) {
     float best = -3.0e38f;
@@ -367,8 +339,6 @@ __device__ __forceinline__ void hfield_geom(const Terrain& T, const CObj& o, con
   int cmin = (int)floor((x0 + T.sx) / T.dx), cmax = (int)ceil((x1 + T.sx) / T.dx);
   int rmin = (int)floor((y0 + T.sy) / T.dy), rmax = (int)ceil((y1 + T.sy) / T.dy);
   cmin = max(cmin, 0); rmin = max(rmin, 0); cmax = min(cmax, T.ncol - 1); rmax = min(rmax, T.nrow - 1);
-  // cosim_create refuses fields whose cells are small against the geoms; the clamp only bounds the loop for the hardware's sake
-  cmax = min(cmax, cmin + HF_MAXCELLS); rmax = min(rmax, rmin + HF_MAXCELLS);
   PrismObj P;
   P.zb = T.gz - base;
   for (int k = 0; k < 3; k++) { P.x[k] = 0.f; P.y[k] = 0.f; P.zt[k] = 0.f; }

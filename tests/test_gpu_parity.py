@@ -620,7 +620,7 @@ def test_humanoid_on_stairs_up_hard_with_position_command():
     n = len(R["qpos"])
     slots = 256
     fits = R["ncon"] <= slots
-    assert R["ncon"].max() >= 100 and np.quantile(R["ncon"], 0.5) >= 20 and fits.mean() > 0.95
+    assert R["ncon"].max() >= 100 and np.quantile(R["ncon"], 0.75) >= 40 and fits.mean() > 0.95
     env = BatchedEnv(cfg, num_envs=n, auto_reset=False, compiled=cm)
     assert env.engine.query("contact_slots") == slots and env.state_dim == 3 * 78 + 2
     target = np.random.default_rng(4).uniform(-3, 3, size=(n, 2)).astype(np.float32)

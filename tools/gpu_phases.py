@@ -1,30 +1,41 @@
 #!/usr/bin/env python3
-"""Per-phase shader-clock profile of the step kernel (diagnostic build with s_memtime stamps; shares, not run times)."""
+"""Per-phase shader-clock profile of the step kernel (diagnostic build with s_memtime stamps; shares, not run times).
+
+    python tools/gpu_phases.py [workload] [settle_steps]      workloads: bench.py's names that have a diagnostic kernel
+"""
 import os, sys
 import numpy as np
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import torch
 from cosim_amd.batched_env import BatchedEnv
 from cosim_amd.config import make_config
-from bench import synthetic_actions
-N = 4096
-cfg = make_config("flamingo_light_v1", num_envs=N, seed=1234)
+from bench import WORKLOADS, synthetic_actions
+wl = sys.argv[1] if len(sys.argv) > 1 else "light_flat"
+settle = int(sys.argv[2]) if len(sys.argv) > 2 else 300
+robot, terrain, hmap, N = WORKLOADS[wl]
+poscmd = wl == "humanoid_stairs"
+cfg = make_config(robot, terrain=terrain, num_envs=N, seed=1234, height_map=hmap, position_command=poscmd)
+if poscmd:
+    cfg["observation"]["command_dim"] = 2
 env = BatchedEnv(cfg, num_envs=N, seed=1234, auto_reset=True, gain_noise=0.1)
-acts = synthetic_actions(N, 0, 340, 4, env.device)
+K = 20
+acts = synthetic_actions(N, 0, settle + K + 20, env.action_dim, env.device)
+env.receive_user_command(np.array([0.5, 0.0, 0.0, 0.0], dtype=np.float32)[:max(env.command_dim, 1)])
 env.reset()
-for t in range(300):
+for t in range(settle):
     env.step(acts[t])
 torch.cuda.synchronize()
 acc = np.zeros(16)
-K = 20
-for t in range(300, 300 + K):
+for t in range(settle, settle + K):
     a = acts[t].contiguous()
     acc += env.engine.profile_step(a.data_ptr(), env._cmd_ptr(), env.state.data_ptr(), env.terminated.data_ptr(), env.truncated.data_ptr())
 acc /= K
 names = ["prologue", "kinematics", "comPos+cdof", "crb (M)", "comVel+rne+sensors", "collision", "constraint rows", "Newton total",
-         "implicitfast+advance", "obs+info epilogue", "  Newton: Hessian (MFMA)", "  Newton: Cholesky+park", "  Newton: tri. solves",
+         "implicitfast+advance", "obs+info epilogue", "  Newton: Hessian (MFMA + contact tree pass)", "  Newton: Cholesky+park", "  Newton: tri. solves",
          "  Newton: line search", "  Newton: move+constraint update", "  implicitfast: factor + solve (rest = advance)"]
 tot = acc[:10].sum()
-print(f"mean wave lifetime {tot:.0f} cycles per control step (4 substeps), diagnostic build, {N} envs resident")
+st = env.solver_stats()
+print(f"{wl}: mean wave lifetime {tot:.0f} cycles per control step ({int(env.cm.blob.frame_skip)} substeps), diagnostic build, {N} envs; "
+      f"contact slots {env.engine.query('contact_slots')}, max contacts seen {st['max_contacts']}, dropped {st['dropped_contacts']}")
 for i in list(range(10)) + [10, 11, 12, 13, 14, 15]:
-    print(f"  {names[i]:34s} {acc[i]:10.0f} cycles  {100*acc[i]/tot:5.1f} %")
+    print(f"  {names[i]:46s} {acc[i]:12.0f} cycles  {100*acc[i]/tot:5.1f} %")
