@@ -221,6 +221,7 @@ struct CtLds {
   // heightfield narrowphase, per geom: end of its (geom, prism) work items in the flattened list, contacts found so far, sub-grid
   // origin, prisms per strip row, lowest point of the geom
   int hf_end[HF ? 24 : 1], hf_cnt[HF ? 24 : 1], hf_cmin[HF ? 24 : 1], hf_rmin[HF ? 24 : 1], hf_ppr[HF ? 24 : 1];
+  int hf_list[HF ? 128 : 1];   // work items the probe pass could not decide, in order, waiting for a full batch
   float hf_lo[HF ? 24 : 1];
 };
 template <bool HF, int NB, int MC, int MCP>
@@ -276,16 +277,66 @@ template <bool CT, bool NRM, class LDS> __device__ __forceinline__ const float* 
 // Lane i < NV holds row i of a symmetric positive definite matrix in a[0..NV).  Right-looking factorisation with the
 // pivot column broadcast by v_readlane; only the lower triangle is meaningful on exit (a[k], k <= i, is L[i][k]; slots
 // k > i hold garbage, which is why no lane masking is needed: 2 VALU per (j,k) pair).  dinv is 1 / L[i][i].
+// Trailing update of one pivot stage, a[K0 .. K0 + N) -= aj * (aj of lanes K0 .. K0 + N): the broadcasts go through scalar registers
+// (v_readlane), and a VALU instruction may read a scalar register only two wait states after a VALU instruction wrote it.  Left to
+// the compiler this became readlane / s_nop 1 / fma per element through ONE scalar register; grouped by four -- four readlanes into
+// four scalars, then the four FMAs -- every FMA sits three instructions behind its readlane and no wait state is spent.
+// (the leading s_nop 0 is the one wait state between the VALU instruction that produced aj and a v_readlane of it; the compiler's
+// hazard recogniser does not look inside inline assembly)
+template <int K0, int N, int NV>
+__device__ __forceinline__ void chol_update(float (&a)[NV], float aj) {
+  if constexpr (N >= 4) {
+    float t0, t1, t2, t3;
+    asm volatile(
+        "s_nop 0\n\tv_readlane_b32 %4, %8, %9\n\tv_readlane_b32 %5, %8, %10\n\tv_readlane_b32 %6, %8, %11\n\tv_readlane_b32 %7, %8, %12\n\t"
+        "v_fma_f32 %0, -%8, %4, %0\n\tv_fma_f32 %1, -%8, %5, %1\n\tv_fma_f32 %2, -%8, %6, %2\n\tv_fma_f32 %3, -%8, %7, %3"
+        : "+v"(a[K0]), "+v"(a[K0 + 1]), "+v"(a[K0 + 2]), "+v"(a[K0 + 3]), "=&s"(t0), "=&s"(t1), "=&s"(t2), "=&s"(t3)
+        : "v"(aj), "n"(K0), "n"(K0 + 1), "n"(K0 + 2), "n"(K0 + 3));
+    chol_update<K0 + 4, N - 4, NV>(a, aj);
+  } else if constexpr (N == 3) {
+    float t0, t1, t2;
+    asm volatile(
+        "s_nop 0\n\tv_readlane_b32 %3, %6, %7\n\tv_readlane_b32 %4, %6, %8\n\tv_readlane_b32 %5, %6, %9\n\t"
+        "v_fma_f32 %0, -%6, %3, %0\n\tv_fma_f32 %1, -%6, %4, %1\n\tv_fma_f32 %2, -%6, %5, %2"
+        : "+v"(a[K0]), "+v"(a[K0 + 1]), "+v"(a[K0 + 2]), "=&s"(t0), "=&s"(t1), "=&s"(t2)
+        : "v"(aj), "n"(K0), "n"(K0 + 1), "n"(K0 + 2));
+  } else if constexpr (N == 2) {
+    float t0, t1;
+    asm volatile(
+        "s_nop 0\n\tv_readlane_b32 %2, %4, %5\n\tv_readlane_b32 %3, %4, %6\n\ts_nop 0\n\t"
+        "v_fma_f32 %0, -%4, %2, %0\n\tv_fma_f32 %1, -%4, %3, %1"
+        : "+v"(a[K0]), "+v"(a[K0 + 1]), "=&s"(t0), "=&s"(t1)
+        : "v"(aj), "n"(K0), "n"(K0 + 1));
+  } else if constexpr (N == 1) {
+    float t0;
+    asm volatile("s_nop 0\n\tv_readlane_b32 %1, %2, %3\n\ts_nop 1\n\tv_fma_f32 %0, -%2, %1, %0" : "+v"(a[K0]), "=&s"(t0) : "v"(aj), "n"(K0));
+  }
+}
+template <int J, int NV>
+__device__ __forceinline__ void chol_stage64(float (&a)[NV], float& dinv, int lane) {
+  if constexpr (J < NV) {
+    const float ajj = rl(a[J], J);
+    const float inv = rsqrtf(fmaxf(ajj, 1e-30f));
+    dinv = (lane == J) ? inv : dinv;
+    a[J] *= inv;  // column J of L in lanes >= J
+    chol_update<J + 1, NV - J - 1, NV>(a, a[J]);
+    chol_stage64<J + 1, NV>(a, dinv, lane);
+  }
+}
 template <int NV, int LW>
 __device__ __forceinline__ void chol_lower(float (&a)[NV], float& dinv, int lane, int hb) {
+  if constexpr (LW == 64) {
+    chol_stage64<0, NV>(a, dinv, lane);
+  } else {
 #pragma unroll
-  for (int j = 0; j < NV; j++) {
-    const float ajj = grp_bcast<LW>(a[j], j, hb);
-    const float inv = rsqrtf(fmaxf(ajj, 1e-30f));
-    dinv = (lane == j) ? inv : dinv;
-    a[j] *= inv;  // column j of L in lanes >= j
+    for (int j = 0; j < NV; j++) {
+      const float ajj = grp_bcast<LW>(a[j], j, hb);
+      const float inv = rsqrtf(fmaxf(ajj, 1e-30f));
+      dinv = (lane == j) ? inv : dinv;
+      a[j] *= inv;  // column j of L in lanes >= j
 #pragma unroll
-    for (int k = j + 1; k < NV; k++) a[k] -= a[j] * grp_bcast<LW>(a[j], k, hb);  // lane k's a[j] = L[k][j]
+      for (int k = j + 1; k < NV; k++) a[k] -= a[j] * grp_bcast<LW>(a[j], k, hb);  // lane k's a[j] = L[k][j]
+    }
   }
 }
 // solve (L L^T) x = b.  L = D L1 with D = diag(L) and L1 unit lower triangular; the LDS matrix holds the strictly lower part
@@ -999,17 +1050,34 @@ __global__ __launch_bounds__(64, (EPW == 2 ? 2 : (163840 / (int)sizeof(typename 
               bool out = !(fabsf(ctr[0]) + fabsf(ctr[1]) + fabsf(ctr[2]) < 1e8f) ||   // non-finite pose (the env is reset at the end of the step)
                          (double)T.sx < lx - rb - margin || -(double)T.sx > lx + rb + margin || (double)T.sy < ly - rb - margin ||
                          -(double)T.sy > ly + rb + margin || T.sz < ctr[2] - T.gz - rb - margin || -base_ > ctr[2] - T.gz + rb + margin;
-              if (!out) {
-                float lo[3], hi[3];
+              float lo[3], hi[3];
+              {
+                // world box around the geom's body-frame box: exact enough to reject, and for hulls also the box the sub-grid is cut
+                // from (six support queries would be six scans of the hull by this one lane; a box that contains the hull only adds
+                // prisms that cannot be hit, the contacts are the same)
+                float m[9];
+                q2m(m, xq);
 #pragma unroll
                 for (int k = 0; k < 3; k++) {
-                  float d[3] = {0.f, 0.f, 0.f}, p_[3];
-                  d[k] = 1.f;
-                  cobj_support<GTM, false>(og, HG, d, p_, ln);
-                  hi[k] = p_[k];
-                  d[k] = -1.f;
-                  cobj_support<GTM, false>(og, HG, d, p_, ln);
-                  lo[k] = p_[k];
+                  const float e = fabsf(m[3 * k]) * R.g_half[0] + fabsf(m[3 * k + 1]) * R.g_half[1] + fabsf(m[3 * k + 2]) * R.g_half[2];
+                  lo[k] = ctr[k] - e; hi[k] = ctr[k] + e;
+                }
+              }
+              // coarse terrain: the highest vertex under the bounding sphere's footprint (a 12 x 12 window at most) against the box's
+              // lowest point
+              if (!out && 2.0 * rb <= 11.0 * T.dx && 2.0 * rb <= 11.0 * T.dy) out = lo[2] - margin > terrain_max_under(T, ctr, rb);
+              if (!out) {
+                if (gt != CS_GEOM_MESH) {
+#pragma unroll
+                  for (int k = 0; k < 3; k++) {
+                    float d[3] = {0.f, 0.f, 0.f}, p_[3];
+                    d[k] = 1.f;
+                    cobj_support<GTM, false>(og, HG, d, p_, ln);
+                    hi[k] = p_[k];
+                    d[k] = -1.f;
+                    cobj_support<GTM, false>(og, HG, d, p_, ln);
+                    lo[k] = p_[k];
+                  }
                 }
                 const double x0 = (double)lo[0] + T.ox, x1 = (double)hi[0] + T.ox, y0 = (double)lo[1] + T.oy, y1 = (double)hi[1] + T.oy;
                 out = x0 - margin > T.sx || x1 + margin < -T.sx || y0 - margin > T.sy || y1 + margin < -T.sy || lo[2] - T.gz - margin > T.sz ||
@@ -1036,41 +1104,44 @@ __global__ __launch_bounds__(64, (EPW == 2 ? 2 : (163840 / (int)sizeof(typename 
             if (ln < 24) { S.hf_end[ln] = end; S.hf_cnt[ln] = 0; }
             const int total = __shfl(end, 23, 64);   // lanes past ngeom add nothing
             WSYNC();
-            int base = 0;
-            while (base < total) {
-              int g0 = 0;
-              while (base >= S.hf_end[g0]) g0++;   // uniform; terminates: base < total = hf_end[23]
-              if (S.hf_cnt[g0] >= 50) { base = S.hf_end[g0]; continue; }   // this geom has its 50 contacts: skip the rest of its prisms
-              const int item = base + ln;
-              bool hit = false;
-              int g = g0;
-              float depth = 0.f, nrm_[3] = {0.f, 0.f, 1.f}, pos_[3] = {0.f, 0.f, 0.f}, gmargin = 0.f;
-              if (item < total) {
-                while (item >= S.hf_end[g]) g++;
-                const int k = item - (g > 0 ? S.hf_end[g > 0 ? g - 1 : 0] : 0), ppr = S.hf_ppr[g], rrow = k / ppr, kk = k - rrow * ppr;
-                const int r = S.hf_rmin[g] + rrow, cmin = S.hf_cmin[g];
-                gmargin = dm.rec[g].g_margin;
-                PrismObj P;
-                P.zb = T.gz - dm.hfield_size[3];
+            // work item -> its geom, the geom's contact margin and the prism (strip vertices kk, kk + 1, kk + 2 of strip row r: vertex v
+            // sits in column cmin + (v >> 1), row r + 1 for even v and r for odd v)
+            auto item_prism = [&](int item, int& g, float& gmargin, PrismObj& P) {
+              while (item >= S.hf_end[g]) g++;
+              const int k = item - (g > 0 ? S.hf_end[g > 0 ? g - 1 : 0] : 0), ppr = S.hf_ppr[g], rrow = k / ppr, kk = k - rrow * ppr;
+              const int r = S.hf_rmin[g] + rrow, cmin = S.hf_cmin[g];
+              gmargin = dm.rec[g].g_margin;
+              P.zb = T.gz - dm.hfield_size[3];
 #pragma unroll
-                for (int i = 0; i < 3; i++) {   // strip vertex kk + i: column cmin + (v >> 1), row r + 1 for even v, r for odd v
-                  const int v = kk + i, c = cmin + (v >> 1), rr = r + 1 - (v & 1);
-                  P.x[i] = (float)(c * T.dx - (double)T.sx - T.ox);
-                  P.y[i] = (float)(rr * T.dy - (double)T.sy - T.oy);
-                  P.zt[i] = T.data[rr * T.ncol + c] * T.sz + T.gz + gmargin;
-                }
-                const float lo2 = S.hf_lo[g];
-                if (!(P.zt[0] < lo2 && P.zt[1] < lo2 && P.zt[2] < lo2) && S.hf_cnt[g] < 50) {
+              for (int i = 0; i < 3; i++) {
+                const int v = kk + i, c = cmin + (v >> 1), rr = r + 1 - (v & 1);
+                P.x[i] = (float)(c * T.dx - (double)T.sx - T.ox);
+                P.y[i] = (float)(rr * T.dy - (double)T.sy - T.oy);
+                P.zt[i] = T.data[rr * T.ncol + c] * T.sz + T.gz + gmargin;
+              }
+            };
+            auto prism_centre = [](const PrismObj& P, float* c1) {
+              c1[0] = (P.x[0] + P.x[1] + P.x[2]) * (1.f / 3.f); c1[1] = (P.y[0] + P.y[1] + P.y[2]) * (1.f / 3.f);
+              c1[2] = (P.zt[0] + P.zt[1] + P.zt[2] + 3.f * P.zb) * (1.f / 6.f);
+            };
+            // full MPR on up to 64 listed items (one per lane, list order = (geom, strip) order) and ordered append of the hits
+            auto run_listed = [&](int cnt) {
+              bool hit = false;
+              int g = 0;
+              float depth = 0.f, nrm_[3] = {0.f, 0.f, 1.f}, pos_[3] = {0.f, 0.f, 0.f}, gmargin = 0.f;
+              if (ln < cnt) {
+                PrismObj P;
+                item_prism(S.hf_list[ln], g, gmargin, P);
+                if (S.hf_cnt[g] < 50) {
                   CObj o;
                   make_cobj(o, g);
-                  const float c1[3] = {(P.x[0] + P.x[1] + P.x[2]) * (1.f / 3.f), (P.y[0] + P.y[1] + P.y[2]) * (1.f / 3.f),
-                                       (P.zt[0] + P.zt[1] + P.zt[2] + 3.f * P.zb) * (1.f / 6.f)};
+                  float c1[3];
+                  prism_centre(P, c1);
                   const MprPrismGeom<GTM, false> sup{P, o, HG, ln};
                   hit = mpr_penetration(sup, c1, o.center, depth, nrm_, pos_) && (nrm_[0] != 0.f || nrm_[1] != 0.f || nrm_[2] != 0.f);
                 }
               }
-              // ordered append: rank of a hit among the hits of its own geom (items are in (geom, strip) order, so lane order is it)
-              int rank_g = 0;
+              int rank_g = 0;   // rank of a hit among the hits of its own geom
               for (unsigned long long rest = __ballot(hit); rest;) {
                 const int gs = __shfl(g, __builtin_ctzll(rest), 64);
                 const unsigned long long same = __ballot(hit && g == gs);
@@ -1089,8 +1160,46 @@ __global__ __launch_bounds__(64, (EPW == 2 ? 2 : (163840 / (int)sizeof(typename 
               if (keep) atomicAdd(&S.hf_cnt[g], 1);
               if (ln == 0) S.ncon_ctr += __popcll(km);
               WSYNC();
+            };
+            int base = 0, nlist = 0;
+            while (base < total) {
+              int g0 = 0;
+              while (base >= S.hf_end[g0]) g0++;   // uniform; terminates: base < total = hf_end[23]
+              if (S.hf_cnt[g0] >= 50) { base = S.hf_end[g0]; continue; }   // this geom has its 50 contacts: skip the rest of its prisms
+              // probe pass: 64 items, each lane decides its prism by height and by the first two exits of MPR; the undecided ones go
+              // to the list in order
+              const int item = base + ln;
+              bool maybe = false;
+              if (item < total) {
+                int g = g0;
+                float gmargin;
+                PrismObj P;
+                item_prism(item, g, gmargin, P);
+                const float lo2 = S.hf_lo[g];
+                if (!(P.zt[0] < lo2 && P.zt[1] < lo2 && P.zt[2] < lo2) && S.hf_cnt[g] < 50) {
+                  CObj o;
+                  make_cobj(o, g);
+                  float c1[3];
+                  prism_centre(P, c1);
+                  const MprPrismGeom<GTM, false> sup{P, o, HG, ln};
+                  maybe = mpr_probe(sup, c1, o.center);
+                }
+              }
+              const unsigned long long mm_ = __ballot(maybe);
+              if (maybe) S.hf_list[nlist + __popcll(mm_ & lanemask_lt(ln))] = item;
+              nlist += __popcll(mm_);
               base += 64;
+              WSYNC();
+              if (nlist >= 64) {
+                run_listed(64);
+                const int moved = (ln + 64 < nlist) ? S.hf_list[ln + 64] : 0;
+                WSYNC();
+                if (ln + 64 < nlist) S.hf_list[ln] = moved;
+                nlist -= 64;
+                WSYNC();
+              }
             }
+            if (nlist > 0) run_listed(nlist);
             ncon = S.ncon_ctr;
             // hulls with few prisms: wave-cooperative, one (geom, prism) at a time (hfield_geom: the same walk, sequential)
             for (unsigned long long cm_ = __ballot(coop_geom); cm_; cm_ &= cm_ - 1) {

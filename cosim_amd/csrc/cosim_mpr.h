@@ -164,6 +164,28 @@ __device__ __forceinline__ real mpr_tri_dist2(const real* x0, const real* B, con
   return dist;
 }
 
+// The first two exits of discoverPortal (no support point beyond the origin along -v0, none along the first portal normal): false
+// = the full routine would return "no penetration" at exactly these points, true = undecided.  Most prisms under a geom's box are
+// decided here; the undecided ones are compacted into dense batches for the full routine.
+template <class SUP>
+__device__ __forceinline__ bool mpr_probe(const SUP& sup, const float* c1, const float* c2) {
+  MprSup p1, p2;
+  real v0[3] = {(real)c1[0] - (real)c2[0], (real)c1[1] - (real)c2[1], (real)c1[2] - (real)c2[2]};
+  real dir[3], dt;
+  if (mpr_vzero(v0)) v0[0] += MPR_EPS * 10.;
+  dir[0] = -v0[0]; dir[1] = -v0[1]; dir[2] = -v0[2];
+  mpr_normalize(dir);
+  sup(dir, p1);
+  dt = mpr_dot(p1.v, dir);
+  if (mpr_zero(dt) || dt < 0.) return false;
+  mpr_cross(dir, v0, p1.v);
+  if (mpr_zero(mpr_dot(dir, dir))) return true;
+  mpr_normalize(dir);
+  sup(dir, p2);
+  dt = mpr_dot(p2.v, dir);
+  return !(mpr_zero(dt) || dt < 0.);
+}
+
 // ccdMPRPenetration: true when the geoms penetrate; depth, dir (geom1 -> geom2) and pos as libccd returns them.
 template <class SUP>
 __device__ __forceinline__ bool mpr_penetration(const SUP& sup, const float* c1, const float* c2, float& depth_out, float* dir_f, float* pos_f) {
