@@ -127,13 +127,16 @@ def cpu_baseline(sample_envs=16, sample_steps=12000):
 
 def pmc_traffic(workload):
     """HBM bytes per launch of the step kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate
-    passes over this same command: tools/pmc_run.sh -> profiles/r01_pmc_summary_v*.txt).  Counters cannot be read from inside
-    the timed run, so the figure is the one measured for the committed kernel; null for workloads without a PMC pass."""
+    passes over this same command: tools/pmc_run.sh -> profiles/rNN_pmc_summary_<workload>.txt).  Counters cannot be read from
+    inside the timed run, so the figure is the one measured for the committed kernel; null for workloads without a PMC pass."""
     import glob
     import re
-    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r*_pmc_summary_v*.txt")),
-                   key=lambda f: [int(x) for x in re.findall(r"\d+", os.path.basename(f))])
-    if workload != "light_flat" or not files:
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
+    files = glob.glob(os.path.join(root, f"r*_pmc_summary_{workload}.txt"))
+    if workload == "light_flat":
+        files += glob.glob(os.path.join(root, "r*_pmc_summary_v*.txt"))           # round-1 naming
+    files.sort(key=lambda f: [int(x) for x in re.findall(r"\d+", os.path.basename(f))])
+    if not files:
         return {"traffic": None}
     vals = {}
     for line in open(files[-1]):
@@ -145,8 +148,8 @@ def pmc_traffic(workload):
     return {"traffic": vals["FETCH_SIZE"] + vals["WRITE_SIZE"],
             "traffic_note": f"bytes per launch, {os.path.basename(files[-1])}: FETCH_SIZE {vals['FETCH_SIZE']:.3g} B (dword-per-lane "
                             "reads, taken at face value: the guide's x2 gfx950 correction is calibrated for 16-B/lane streaming "
-                            f"reads only) + WRITE_SIZE {vals['WRITE_SIZE']:.3g} B (mostly write-back of the register-spill "
-                            "scratch, ~76 B/lane x 262144 lanes)"}
+                            f"reads only) + WRITE_SIZE {vals['WRITE_SIZE']:.3g} B (state write-back plus the write-back of "
+                            "register-spill scratch)"}
 
 
 def free_port():

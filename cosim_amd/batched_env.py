@@ -111,6 +111,8 @@ class BatchedEnv:
                 self.engine.set_param("contact_twist", np.array([1.0]))
             except (ValueError, RuntimeError):
                 pass
+        if os.environ.get("COSIM_LS_SCALE"):                   # line-search gradient tolerance multiplier (tuning runs)
+            self.engine.set_param("ls_tolerance_scale", np.array([float(os.environ["COSIM_LS_SCALE"])]))
         if os.environ.get("COSIM_PAIR_MODE"):                  # "1": hull pairs wave-cooperative (A/B runs)
             self.engine.set_param("pair_mode", np.array([float(os.environ["COSIM_PAIR_MODE"])]))
         epw = os.environ.get("COSIM_ENVS_PER_WAVE")

@@ -43,6 +43,7 @@ struct cosim_engine {
   uint64_t seed = 0;
   int64_t env_id0 = 0;
   float tol32 = 1e-6f;
+  float ls_scale = 1.f;
   int max_newton = 50;
   int max_ls = 24;
   int nsub_override = 0;
@@ -518,6 +519,7 @@ int cosim_set_param(cosim_engine_t* e, const char* name, const float* host, int 
   else if (n == "kd") { off = L.p_kd; width = m.nu; }
   else if (n == "meaninertia") { off = L.p_mean; width = 1; }
   else if (n == "solver_tolerance") { e->tol32 = host[0]; return COSIM_OK; }
+  else if (n == "ls_tolerance_scale") { e->ls_scale = host[0]; return COSIM_OK; }
   else if (n == "max_newton") { e->max_newton = (int)host[0]; return COSIM_OK; }
   else if (n == "max_ls") { e->max_ls = (int)host[0]; return COSIM_OK; }
   else if (n == "wave_priority") {   // [usual Newton iterations per substep, lag thresholds of priority 1, 2, 3]; a huge first threshold switches it off
@@ -568,7 +570,7 @@ static KArgs base_args(cosim_engine* e) {
   a.hull_vert = e->d_hull_vert; a.hull_adr = e->d_hull_adr; a.hull_nbr = e->d_hull_nbr; a.hfield = e->d_hfield;
   a.pairs = e->d_pairs; a.gext = e->d_gext;
   a.n_envs = e->n_envs; a.seed_lo = (unsigned)e->seed; a.seed_hi = (unsigned)(e->seed >> 32); a.env_id0 = e->env_id0;
-  a.tol32 = e->tol32; a.max_newton = e->max_newton; a.max_ls = e->max_ls; a.nsub_override = e->nsub_override; a.pair_coop = e->pair_coop;
+  a.tol32 = e->tol32; a.ls_scale = e->ls_scale; a.max_newton = e->max_newton; a.max_ls = e->max_ls; a.nsub_override = e->nsub_override; a.pair_coop = e->pair_coop;
   for (int k = 0; k < 4; k++) a.prio[k] = e->prio[k];
   return a;
 }
@@ -706,9 +708,9 @@ int cosim_profile_step(cosim_engine_t* e, const float* actions_dev, const float*
   (e->epw == 2 ? e->launch_prof2 : e->launch_prof)(e, a, e->n_envs, 0);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipDeviceSynchronize());
-  unsigned long long raw[16];
+  unsigned long long raw[24];
   HIP_TRY(hipMemcpy(raw, e->d_dbg, sizeof raw, hipMemcpyDeviceToHost));
-  for (int i = 0; i < 16; i++) cycles_out16[i] = (double)raw[i] / (double)(e->n_envs / e->epw);   // per wave
+  for (int i = 0; i < 24; i++) cycles_out16[i] = (double)raw[i] / (double)(e->n_envs / e->epw);   // per wave
   return COSIM_OK;
 }
 

@@ -60,6 +60,7 @@ struct KArgs {
   unsigned seed_lo, seed_hi;
   long long env_id0;
   float tol32;            // fp32 solver tolerance
+  float ls_scale;         // multiplies the line search's gradient tolerance (tol32 * ls_tolerance * |s| / scale)
   int max_newton, max_ls;
   int nsub_override;      // > 0: physics substeps per control step (diagnostics; 0 = the model's frame_skip)
   int pair_coop;          // robot-robot pairs with a hull: 1 = one at a time, wave-cooperative vertex scans; 0 = lane-parallel
@@ -571,8 +572,10 @@ __global__ __launch_bounds__(64, (EPW == 2 ? 2 : (163840 / (int)sizeof(typename 
   const int nbody = dm.nbody, nu = dm.nu, nq = dm.nq, ngeom = dm.ngeom;
   const float h = dm.timestep;
   // diagnostic build only: shader-clock time per phase, summed over the substeps (never executed in the product kernel)
-  unsigned long long pt0 = 0, pacc[16];
-  if (PROF) { for (int i = 0; i < 16; i++) pacc[i] = 0; pt0 = __builtin_amdgcn_s_memtime(); }
+  unsigned long long pt0 = 0, pacc[16], pext[8];   // pext: heightfield narrowphase: cycles in [0] sub-grids [1] probe passes [2] full-MPR batches; counts [3] work items [4] probe batches [5] probes run [6] full batches [7] full MPRs run
+  if (PROF) { for (int i = 0; i < 16; i++) pacc[i] = 0; for (int i = 0; i < 8; i++) pext[i] = 0; pt0 = __builtin_amdgcn_s_memtime(); }
+#define PEXT_T0() unsigned long long pe0_ = 0; if (PROF) { __builtin_amdgcn_s_waitcnt(0); pe0_ = __builtin_amdgcn_s_memtime(); }
+#define PEXT_ADD(i) do { if (PROF) { __builtin_amdgcn_s_waitcnt(0); unsigned long long t_ = __builtin_amdgcn_s_memtime(); pext[i] += t_ - pe0_; pe0_ = t_; } } while (0)
 #define STAMP(i) do { KARGS_FENCE(); if (PROF) { __builtin_amdgcn_s_waitcnt(0); unsigned long long t_ = __builtin_amdgcn_s_memtime(); pacc[i] += t_ - pt0; pt0 = t_; } } while (0)
 
   // ---- per-env parameters -> LDS
@@ -1039,6 +1042,7 @@ __global__ __launch_bounds__(64, (EPW == 2 ? 2 : (163840 / (int)sizeof(typename 
           static_assert(!HF || CT, "heightfield kernels run in contact-twist mode");
           if constexpr (CT) {
             if (ln == 0) S.ncon_ctr = 0;
+            PEXT_T0();
             int n_items = 0;
             bool coop_geom = false;
             if (active) {
@@ -1104,6 +1108,8 @@ __global__ __launch_bounds__(64, (EPW == 2 ? 2 : (163840 / (int)sizeof(typename 
             if (ln < 24) { S.hf_end[ln] = end; S.hf_cnt[ln] = 0; }
             const int total = __shfl(end, 23, 64);   // lanes past ngeom add nothing
             WSYNC();
+            PEXT_ADD(0);
+            if (PROF) pext[3] += total;
             // work item -> its geom, the geom's contact margin and the prism (strip vertices kk, kk + 1, kk + 2 of strip row r: vertex v
             // sits in column cmin + (v >> 1), row r + 1 for even v and r for odd v)
             auto item_prism = [&](int item, int& g, float& gmargin, PrismObj& P) {
@@ -1169,7 +1175,7 @@ __global__ __launch_bounds__(64, (EPW == 2 ? 2 : (163840 / (int)sizeof(typename 
               // probe pass: 64 items, each lane decides its prism by height and by the first two exits of MPR; the undecided ones go
               // to the list in order
               const int item = base + ln;
-              bool maybe = false;
+              bool maybe = false, probed = false;
               if (item < total) {
                 int g = g0;
                 float gmargin;
@@ -1183,6 +1189,7 @@ __global__ __launch_bounds__(64, (EPW == 2 ? 2 : (163840 / (int)sizeof(typename 
                   prism_centre(P, c1);
                   const MprPrismGeom<GTM, false> sup{P, o, HG, ln};
                   maybe = mpr_probe(sup, c1, o.center);
+                  probed = true;
                 }
               }
               const unsigned long long mm_ = __ballot(maybe);
@@ -1190,8 +1197,12 @@ __global__ __launch_bounds__(64, (EPW == 2 ? 2 : (163840 / (int)sizeof(typename 
               nlist += __popcll(mm_);
               base += 64;
               WSYNC();
+              PEXT_ADD(1);
+              if (PROF) { pext[4] += 1; pext[5] += __popcll(__ballot(probed)); }
               if (nlist >= 64) {
+                if (PROF) { pext[6] += 1; pext[7] += 64; }
                 run_listed(64);
+                PEXT_ADD(2);
                 const int moved = (ln + 64 < nlist) ? S.hf_list[ln + 64] : 0;
                 WSYNC();
                 if (ln + 64 < nlist) S.hf_list[ln] = moved;
@@ -1199,7 +1210,11 @@ __global__ __launch_bounds__(64, (EPW == 2 ? 2 : (163840 / (int)sizeof(typename 
                 WSYNC();
               }
             }
-            if (nlist > 0) run_listed(nlist);
+            if (nlist > 0) {
+              if (PROF) { pext[6] += 1; pext[7] += nlist; }
+              run_listed(nlist);
+              PEXT_ADD(2);
+            }
             ncon = S.ncon_ctr;
             // hulls with few prisms: wave-cooperative, one (geom, prism) at a time (hfield_geom: the same walk, sequential)
             for (unsigned long long cm_ = __ballot(coop_geom); cm_; cm_ &= cm_ - 1) {
@@ -1945,7 +1960,7 @@ __global__ __launch_bounds__(64, (EPW == 2 ? 2 : (163840 / (int)sizeof(typename 
         const float snorm = sqrtf(grp_sum<LW>(sr_l * sr_l));
         if (!(snorm >= 1e-20f)) return false;
         const float qG1 = grp_sum<LW>(sr_l * (Ma - qsm_l)), qG2 = grp_sum<LW>(0.5f * sr_l * Mv);
-        const float gtol = A.tol32 * dm.ls_tolerance * snorm / scale;
+        const float gtol = A.tol32 * A.ls_scale * dm.ls_tolerance * snorm / scale;
         struct Pnt { float alpha, cost, d0, d1, step; };   // step = -d0 / d1 (Newton step of the 1-D search; v_rcp_f32: 1 ulp is ample)
         auto eval = [&](float alpha) -> Pnt {
           float c0 = 0.f, c1 = 0.f, c2 = 0.f;
@@ -2346,7 +2361,10 @@ __global__ __launch_bounds__(64, (EPW == 2 ? 2 : (163840 / (int)sizeof(typename 
   // =============================================================== state write-back
   STAMP(9);   // observation build + info
   if (PROF && A.dbg != nullptr && wlane == 0)
+  {
     for (int i = 0; i < 16; i++) atomicAdd(reinterpret_cast<unsigned long long*>(A.dbg) + i, pacc[i]);
+    for (int i = 0; i < 8; i++) atomicAdd(reinterpret_cast<unsigned long long*>(A.dbg) + 16 + i, pext[i]);
+  }
   if (lane < nq) rec[lay.s_qpos + lane] = S.qpos[lane];
   if (lane < NV) { rec[lay.s_qvel + lane] = S.qvel[lane]; rec[lay.s_warm + lane] = S.qacc[lane]; }
   if (lane < nu) rec[lay.s_lastact + lane] = do_reset ? 0.f : S.act[lane];

@@ -25,7 +25,7 @@ env.reset()
 for t in range(settle):
     env.step(acts[t])
 torch.cuda.synchronize()
-acc = np.zeros(16)
+acc = np.zeros(24)
 for t in range(settle, settle + K):
     a = acts[t].contiguous()
     acc += env.engine.profile_step(a.data_ptr(), env._cmd_ptr(), env.state.data_ptr(), env.terminated.data_ptr(), env.truncated.data_ptr())
@@ -39,3 +39,8 @@ print(f"{wl}: mean wave lifetime {tot:.0f} cycles per control step ({int(env.cm.
       f"contact slots {env.engine.query('contact_slots')}, max contacts seen {st['max_contacts']}, dropped {st['dropped_contacts']}")
 for i in list(range(10)) + [10, 11, 12, 13, 14, 15]:
     print(f"  {names[i]:46s} {acc[i]:12.0f} cycles  {100*acc[i]/tot:5.1f} %")
+if acc[19] > 0:
+    sub = int(env.cm.blob.frame_skip)
+    print(f"  heightfield narrowphase per substep: {acc[19]/sub:.0f} work items, {acc[20]/sub:.1f} probe batches ({acc[21]/sub:.0f} probes run), "
+          f"{acc[22]/sub:.1f} full-MPR batches ({acc[23]/sub:.0f} MPRs run); cycles: sub-grids {acc[16]/sub:.0f}, probe passes {acc[17]/sub:.0f}, "
+          f"full batches {acc[18]/sub:.0f}")

@@ -1,29 +1,53 @@
 #!/bin/bash
-# PMC passes for the step kernel (separate rocprofv3 runs, counters only; no trace domains mixed in).
-# usage on the GPU box: bash tools/pmc_run.sh <tag>
+# Kernel trace + PMC passes for the step kernel of one bench workload (separate rocprofv3 runs; counters never mixed with trace
+# domains).  usage on the GPU box:  bash tools/pmc_run.sh <tag> [workload] [steps]
+# Writes gpurun_out/prof_<tag>_<workload>/{kernel_stats.csv,kernel_trace_summary.txt,pmc_summary.txt}; copy what is to be judged
+# into profiles/.
 set -u
-TAG=${1:-r01}
-OUT=$GRAFT_REPO_ROOT/gpurun_out/pmc_$TAG
+TAG=${1:-r02}
+WL=${2:-light_flat}
+STEPS=${3:-40}
+OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_${TAG}_${WL}
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-CMD="python3 $GRAFT_REPO_ROOT/bench.py --steps 40 --warmup 10 --no-cpu-baseline"
+ARGS="$GRAFT_REPO_ROOT/bench.py --workload $WL --steps $STEPS --warmup 10 --no-cpu-baseline"
+# 1. kernel trace + stats (per-kernel durations)
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ARGS > $OUT/trace.log 2>&1 || echo "trace pass failed"
+grep '^{' $OUT/trace.log | tail -n 1 > $OUT/bench_line.json
+# 2. counters, one pass per set
 i=0
 for set in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVE_CYCLES" \
            "SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_WAIT_INST_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" \
            "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_FLAT SQ_INST_CYCLES_VMEM GRBM_GUI_ACTIVE" \
            "FETCH_SIZE" "WRITE_SIZE"; do
   i=$((i+1))
-  rocprofv3 --pmc $set --output-format csv -d $OUT/pass$i -- $CMD > $OUT/pass$i.log 2>&1 || echo "pass $i failed"
+  rocprofv3 --pmc $set --output-format csv -d $OUT/pass$i -- python3 $ARGS > $OUT/pass$i.log 2>&1 || echo "pmc pass $i failed"
 done
 python3 - <<PY
-import csv, glob, collections
+import csv, glob, collections, os
+out = "$OUT"
+# kernel stats: per kernel name calls, total, average (ns)
+rows = collections.defaultdict(list)
+for f in glob.glob(out + "/trace/*/*kernel_trace.csv"):
+    for r in csv.DictReader(open(f)):
+        rows[r["Kernel_Name"]].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+with open(out + "/kernel_trace_summary.txt", "w") as o:
+    o.write("rocprofv3 --kernel-trace --stats -- python3 bench.py --workload $WL --steps $STEPS --warmup 10 --no-cpu-baseline\n")
+    o.write(f"{'kernel':110s} {'calls':>6s} {'avg_us':>10s} {'min_us':>10s} {'max_us':>10s} {'total_ms':>10s}\n")
+    for k, v in sorted(rows.items(), key=lambda kv: -sum(kv[1])):
+        o.write(f"{k[:110]:110s} {len(v):6d} {sum(v)/len(v)/1e3:10.2f} {min(v)/1e3:10.2f} {max(v)/1e3:10.2f} {sum(v)/1e6:10.3f}\n")
+for f in glob.glob(out + "/trace/*/*kernel_stats.csv"):
+    os.replace(f, out + "/kernel_stats.csv")
 tot = collections.defaultdict(float); cnt = collections.defaultdict(int)
-for f in glob.glob("$OUT/pass*/*/*counter_collection.csv"):
+for f in glob.glob(out + "/pass*/*/*counter_collection.csv"):
     for r in csv.DictReader(open(f)):
         if "env_kernel" in r["Kernel_Name"]:
             tot[r["Counter_Name"]] += float(r["Counter_Value"]); cnt[r["Counter_Name"]] += 1
-with open("$OUT/summary.txt", "w") as o:
+with open(out + "/pmc_summary.txt", "w") as o:
+    o.write("per launch of cosim::env_kernel, rocprofv3 --pmc passes over: bench.py --workload $WL --steps $STEPS --warmup 10\n")
     for k in sorted(tot):
         o.write(f"{k:28s} per-launch {tot[k]/cnt[k]:16.1f}   launches {cnt[k]}\n")
-print(open("$OUT/summary.txt").read())
+print(open(out + "/kernel_trace_summary.txt").read()[:3000])
+print(open(out + "/pmc_summary.txt").read())
+print(open(out + "/bench_line.json").read()[:600])
 PY
