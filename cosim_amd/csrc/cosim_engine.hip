@@ -365,6 +365,24 @@ int cosim_mlp_forward(const float* x_dev, int n, int n_layers, const int* dims, 
   return COSIM_OK;
 }
 
+int cosim_lstm_cell(const float* x_dev, const float* h_dev, const float* c_dev, int n, int in_dim, int hidden, const float* w_dev,
+                    const float* r_dev, const float* b_dev, float* h_out_dev, float* c_out_dev, void* stream) {
+  if (!x_dev || !h_dev || !c_dev || !w_dev || !r_dev || !h_out_dev || !c_out_dev || n <= 0) return fail(COSIM_EINVAL, "cosim_lstm_cell: bad argument");
+  if (in_dim < 1 || hidden < 1 || in_dim + hidden > 1200) return fail(COSIM_EINVAL, "cosim_lstm_cell: in_dim + hidden outside 2..1200");
+  LstmArgs a;
+  a.x = x_dev; a.h = h_dev; a.c = c_dev; a.W = w_dev; a.R = r_dev; a.B = b_dev; a.h_out = h_out_dev; a.c_out = c_out_dev;
+  a.n = n; a.I = in_dim; a.H = hidden; a.ld = (in_dim + hidden) | 1;
+  const size_t lds = (size_t)32 * a.ld * sizeof(float);
+  static size_t lds_allowed = 0;
+  if (lds > lds_allowed) {
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_cell_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    lds_allowed = lds;
+  }
+  hipLaunchKernelGGL(lstm_cell_kernel, dim3((n + 31) / 32), dim3(256), lds, (hipStream_t)stream, a);
+  HIP_TRY(hipGetLastError());
+  return COSIM_OK;
+}
+
 int cosim_fleet_stats(const float* info_dev, int n, int info_dim, int nu, const float* cmd_dev, int cmd_stride, int ncmd, double* acc_dev,
                       void* stream) {
   if (!info_dev || !acc_dev || n <= 0 || nu < 0 || ncmd < 0 || ncmd > 3 || 4 + nu + ncmd > 32 || info_dim < 4 + nu || (ncmd > 0 && !cmd_dev))

@@ -223,6 +223,8 @@ struct CtLds {
   // origin, prisms per strip row, lowest point of the geom
   int hf_end[HF ? 24 : 1], hf_cnt[HF ? 24 : 1], hf_cmin[HF ? 24 : 1], hf_rmin[HF ? 24 : 1], hf_ppr[HF ? 24 : 1];
   int hf_list[HF ? 128 : 1];   // work items the probe pass could not decide, in order, waiting for a full batch
+  int hf_zlist[HF ? 128 : 1];  // work items that passed the height test, in order, waiting for a full probe batch
+  float hf_mg[HF ? 24 : 1];    // per geom: contact margin
   float hf_lo[HF ? 24 : 1];
 };
 template <bool HF, int NB, int MC, int MCP>
@@ -952,12 +954,14 @@ __global__ __launch_bounds__(64, (EPW == 2 ? 2 : (163840 / (int)sizeof(typename 
       int ncon = 0;
       int npc = 0;   // CT: robot-robot contacts (slots of their own, dense rows); otherwise they follow the ground contacts in ncon
       const HullGraph HG{A.hull_vert, A.hull_adr, A.hull_nbr};
+      const float4* const gext_ = A.gext;   // (locals, so that the lambdas below do not capture the argument-block pointer)
+      const float* const hfdata_ = A.hfield;
       // world pose of geom g as a convex object (mesh: body frame, vertices in body coordinates; primitive: geom frame)
       auto make_cobj = [&](CObj& o, int g) {
         const LaneRec& G = dm.rec[g];
         const int gb = G.g_body;
         const float bq[4] = {S.xquat[gb][0], S.xquat[gb][1], S.xquat[gb][2], S.xquat[gb][3]};
-        const float4 ge = A.gext[g];
+        const float4 ge = gext_[g];
         const float cl[3] = {ge.x, ge.y, ge.z};
         float v[3];
         qrot(v, bq, cl);
@@ -977,7 +981,7 @@ __global__ __launch_bounds__(64, (EPW == 2 ? 2 : (163840 / (int)sizeof(typename 
         const LaneRec& R = dm.rec[ln];
         constexpr bool is_plane = !HF;
         Terrain T;
-        T.data = A.hfield; T.nrow = dm.hfield_nrow; T.ncol = dm.hfield_ncol;
+        T.data = hfdata_; T.nrow = dm.hfield_nrow; T.ncol = dm.hfield_ncol;
         T.sx = dm.hfield_size[0]; T.sy = dm.hfield_size[1]; T.sz = dm.hfield_size[2]; T.gz = dm.ground_pos[2];
         T.ox = (double)S.qpos[0] - (double)dm.ground_pos[0]; T.oy = (double)S.qpos[1] - (double)dm.ground_pos[1];
         T.dx = is_plane ? 1.0 : 2.0 * (double)T.sx / (double)(T.ncol - 1); T.dy = is_plane ? 1.0 : 2.0 * (double)T.sy / (double)(T.nrow - 1);
@@ -1094,7 +1098,7 @@ __global__ __launch_bounds__(64, (EPW == 2 ? 2 : (163840 / (int)sizeof(typename 
                   if (ppr > 0 && (rmax - rmin) * ppr > 32768) { rmax = rmin + 32768 / ppr; st_dropcon++; }   // bounded walk (a 0.6 m x 0.6 m footprint of 1 cm cells fits); counted
                   if (rmax > rmin && ppr > 0) {
                     n_items = (rmax - rmin) * ppr;
-                    S.hf_cmin[ln] = cmin; S.hf_rmin[ln] = rmin; S.hf_ppr[ln] = ppr; S.hf_lo[ln] = lo[2];
+                    S.hf_cmin[ln] = cmin; S.hf_rmin[ln] = rmin; S.hf_ppr[ln] = ppr; S.hf_lo[ln] = lo[2]; S.hf_mg[ln] = margin;
                     // a hull with only a few prisms under it (coarse terrain): its prisms one at a time with all 64 lanes sharing the
                     // vertex scans -- 64 lanes each scanning a 700-vertex hull for a handful of items would cost more
                     if (gt == CS_GEOM_MESH && n_items < 32 && R.g_hullnum > 64) { coop_geom = true; n_items = 0; }
@@ -1106,7 +1110,7 @@ __global__ __launch_bounds__(64, (EPW == 2 ? 2 : (163840 / (int)sizeof(typename 
 #pragma unroll
             for (int o = 1; o < 32; o <<= 1) { const int t = __shfl_up(end, o, 64); if (ln >= o) end += t; }
             if (ln < 24) { S.hf_end[ln] = end; S.hf_cnt[ln] = 0; }
-            const int total = __shfl(end, 23, 64);   // lanes past ngeom add nothing
+            const int total = __builtin_amdgcn_readlane(end, 23);   // lanes past ngeom add nothing
             WSYNC();
             PEXT_ADD(0);
             if (PROF) pext[3] += total;
@@ -1116,7 +1120,7 @@ __global__ __launch_bounds__(64, (EPW == 2 ? 2 : (163840 / (int)sizeof(typename 
               while (item >= S.hf_end[g]) g++;
               const int k = item - (g > 0 ? S.hf_end[g > 0 ? g - 1 : 0] : 0), ppr = S.hf_ppr[g], rrow = k / ppr, kk = k - rrow * ppr;
               const int r = S.hf_rmin[g] + rrow, cmin = S.hf_cmin[g];
-              gmargin = dm.rec[g].g_margin;
+              gmargin = S.hf_mg[g];
               P.zb = T.gz - dm.hfield_size[3];
 #pragma unroll
               for (int i = 0; i < 3; i++) {
@@ -1167,54 +1171,91 @@ __global__ __launch_bounds__(64, (EPW == 2 ? 2 : (163840 / (int)sizeof(typename 
               if (ln == 0) S.ncon_ctr += __popcll(km);
               WSYNC();
             };
-            int base = 0, nlist = 0;
-            while (base < total) {
-              int g0 = 0;
-              while (base >= S.hf_end[g0]) g0++;   // uniform; terminates: base < total = hf_end[23]
-              if (S.hf_cnt[g0] >= 50) { base = S.hf_end[g0]; continue; }   // this geom has its 50 contacts: skip the rest of its prisms
-              // probe pass: 64 items, each lane decides its prism by height and by the first two exits of MPR; the undecided ones go
-              // to the list in order
-              const int item = base + ln;
-              bool maybe = false, probed = false;
-              if (item < total) {
-                int g = g0;
+            // probe pass on up to 64 height-test survivors (one per lane, in order): MPR's first two exits decide most of them, the
+            // undecided ones go to the second list
+            int nlist = 0, nz = 0;
+            auto flush_full = [&](bool all) {
+              while (nlist >= 64 || (all && nlist > 0)) {
+                const int cnt = min(nlist, 64);
+                if (PROF) { pext[6] += 1; pext[7] += cnt; }
+                run_listed(cnt);
+                PEXT_ADD(2);
+                const int moved = (ln + 64 < nlist) ? S.hf_list[ln + 64] : 0;
+                WSYNC();
+                if (ln + 64 < nlist) S.hf_list[ln] = moved;
+                nlist -= cnt;
+                WSYNC();
+              }
+            };
+            auto probe_listed = [&](int cnt) {
+              bool maybe = false;
+              int item = 0;
+              if (ln < cnt) {
+                item = S.hf_zlist[ln];
+                int g = 0;
                 float gmargin;
                 PrismObj P;
                 item_prism(item, g, gmargin, P);
-                const float lo2 = S.hf_lo[g];
-                if (!(P.zt[0] < lo2 && P.zt[1] < lo2 && P.zt[2] < lo2) && S.hf_cnt[g] < 50) {
+                if (S.hf_cnt[g] < 50) {
                   CObj o;
                   make_cobj(o, g);
                   float c1[3];
                   prism_centre(P, c1);
                   const MprPrismGeom<GTM, false> sup{P, o, HG, ln};
                   maybe = mpr_probe(sup, c1, o.center);
-                  probed = true;
                 }
               }
               const unsigned long long mm_ = __ballot(maybe);
               if (maybe) S.hf_list[nlist + __popcll(mm_ & lanemask_lt(ln))] = item;
               nlist += __popcll(mm_);
-              base += 64;
               WSYNC();
               PEXT_ADD(1);
-              if (PROF) { pext[4] += 1; pext[5] += __popcll(__ballot(probed)); }
-              if (nlist >= 64) {
-                if (PROF) { pext[6] += 1; pext[7] += 64; }
-                run_listed(64);
-                PEXT_ADD(2);
-                const int moved = (ln + 64 < nlist) ? S.hf_list[ln + 64] : 0;
+              if (PROF) { pext[4] += 1; pext[5] += cnt; }
+              flush_full(false);
+            };
+            auto flush_probe = [&](bool all) {
+              while (nz >= 64 || (all && nz > 0)) {
+                const int cnt = min(nz, 64);
+                probe_listed(cnt);
+                const int moved = (ln + 64 < nz) ? S.hf_zlist[ln + 64] : 0;
                 WSYNC();
-                if (ln + 64 < nlist) S.hf_list[ln] = moved;
-                nlist -= 64;
+                if (ln + 64 < nz) S.hf_zlist[ln] = moved;
+                nz -= cnt;
                 WSYNC();
               }
+            };
+            int base = 0;
+            while (base < total) {
+              int g0 = 0;
+              while (base >= __builtin_amdgcn_readfirstlane(S.hf_end[g0])) g0++;   // uniform; terminates: base < total = hf_end[23]
+              if (__builtin_amdgcn_readfirstlane(S.hf_cnt[g0]) >= 50) { base = __builtin_amdgcn_readfirstlane(S.hf_end[g0]); continue; }   // this geom has its 50 contacts: skip the rest of its prisms
+              // height pass: 64 items; a prism whose top lies entirely below the geom's lowest point cannot touch it (mjc_ConvexHField's
+              // own test) -- three loads and three compares per item, the survivors are listed in order
+              const int item = base + ln;
+              bool alive = false;
+              if (item < total) {
+                int g = g0;
+                while (item >= S.hf_end[g]) g++;
+                const int k = item - (g > 0 ? S.hf_end[g > 0 ? g - 1 : 0] : 0), ppr = S.hf_ppr[g], rrow = k / ppr, kk = k - rrow * ppr;
+                const int r = S.hf_rmin[g] + rrow, cmin = S.hf_cmin[g];
+                const float lo2 = S.hf_lo[g], add = T.gz + S.hf_mg[g];
+                bool below = true;
+#pragma unroll
+                for (int i = 0; i < 3; i++) {
+                  const int v = kk + i, c = cmin + (v >> 1), rr = r + 1 - (v & 1);
+                  below = below && (T.data[rr * T.ncol + c] * T.sz + add < lo2);
+                }
+                alive = !below && S.hf_cnt[g] < 50;
+              }
+              const unsigned long long am = __ballot(alive);
+              if (alive) S.hf_zlist[nz + __popcll(am & lanemask_lt(ln))] = item;
+              nz += __popcll(am);
+              base += 64;
+              WSYNC();
+              flush_probe(false);
             }
-            if (nlist > 0) {
-              if (PROF) { pext[6] += 1; pext[7] += nlist; }
-              run_listed(nlist);
-              PEXT_ADD(2);
-            }
+            flush_probe(true);
+            flush_full(true);
             ncon = S.ncon_ctr;
             // hulls with few prisms: wave-cooperative, one (geom, prism) at a time (hfield_geom: the same walk, sequential)
             for (unsigned long long cm_ = __ballot(coop_geom); cm_; cm_ &= cm_ - 1) {

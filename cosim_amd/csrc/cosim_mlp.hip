@@ -100,6 +100,65 @@ __global__ __launch_bounds__(256) void mlp_forward_kernel(MlpArgs A) {
   }
 }
 
+// One LSTM cell step for N environments (the recurrent policy of core/policy.py:24-47: the ONNX LSTM node with sequence length 1,
+// one direction, default activations; gate order i, o, f, c as ONNX lays W / R / B out).  A workgroup takes 32 environments: [x | h]
+// staged in LDS once, each wave owns 32 hidden units at a time and accumulates their four gates (x W^T + h R^T + Wb + Rb) as four
+// 32 x 32 tiles on the matrix pipe, then applies c' = sigma(f) c + sigma(i) tanh(g), h' = sigma(o) tanh(c') in registers.
+struct LstmArgs {
+  const float *x, *h, *c;      // [n, I], [n, H], [n, H]
+  const float *W, *R, *B;      // [4H, I], [4H, H], [8H] (Wb then Rb) or null
+  float *h_out, *c_out;        // [n, H]; may alias h / c (each element is read before the workgroup that owns its rows writes it)
+  int n, I, H, ld;
+};
+
+__global__ __launch_bounds__(256) void lstm_cell_kernel(LstmArgs A) {
+  typedef float f32x16 __attribute__((ext_vector_type(16)));
+  extern __shared__ float lstm_lds[];   // [32][ld]: x then h of 32 environments
+  const int t = threadIdx.x, l = t & 63, wave = t >> 6, n0 = blockIdx.x * 32, I = A.I, H = A.H, K = I + H, ld = A.ld;
+  for (int e = t; e < 32 * K; e += 256) {
+    const int r = e / K, k = e - r * K;
+    float v = 0.f;
+    if (n0 + r < A.n) v = k < I ? A.x[(size_t)(n0 + r) * I + k] : A.h[(size_t)(n0 + r) * H + (k - I)];
+    lstm_lds[r * ld + k] = v;
+  }
+  __syncthreads();
+  const int row_a = l & 31, kk = l >> 5;
+  // every c this workgroup needs is read before any of its h / c is written (in-place update across launches is safe; h_out may
+  // alias h because h was staged in LDS above and other workgroups own other rows)
+  for (int ti = wave; ti * 32 < H; ti += 4) {
+    const int col = ti * 32 + (l & 31);
+    const bool cok = col < H;
+    f32x16 acc[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const float bias = (A.B != nullptr && cok) ? A.B[q * H + col] + A.B[4 * H + q * H + col] : 0.f;
+#pragma unroll
+      for (int v = 0; v < 16; v++) acc[q][v] = bias;
+    }
+    for (int k0 = 0; k0 < K; k0 += 2) {
+      const int k = k0 + kk;
+      const float a = k < K ? lstm_lds[row_a * ld + k] : 0.f;
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        float w = 0.f;
+        if (cok && k < K) w = k < I ? A.W[(size_t)(q * H + col) * I + k] : A.R[(size_t)(q * H + col) * H + (k - I)];
+        acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, w, acc[q], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int v = 0; v < 16; v++) {
+      const int row = (v & 3) + 8 * (v >> 2) + 4 * (l >> 5);
+      if (cok && n0 + row < A.n) {
+        const size_t o = (size_t)(n0 + row) * H + col;
+        const float ig = 1.f / (1.f + expf(-acc[0][v])), og = 1.f / (1.f + expf(-acc[1][v])), fg = 1.f / (1.f + expf(-acc[2][v]));
+        const float cn = fg * A.c[o] + ig * tanhf(acc[3][v]);
+        A.c_out[o] = cn;
+        A.h_out[o] = og * tanhf(cn);
+      }
+    }
+  }
+}
+
 // Reporter side of the loop (core/reporter.py:210-218, 429-442, 506-508): count / sum / sum of squares per metric column over
 // the fleet in one launch.  Columns: info[0..4) as they are, |torque| (info[4 .. 4 + nu)), |command_i - measured_i| for
 // i < ncmd (measured = lin_vel_x, lin_vel_y, ang_vel_yaw = info[1 + i]).  acc is [3][K] doubles, K = 4 + nu + ncmd <= 32.

@@ -246,6 +246,12 @@ class OnnxGraph:
         Bv = x[3][0] if len(x) > 3 and x[3] is not None else t.zeros(8 * H, device=X.device)
         h = x[5][0] if len(x) > 5 and x[5] is not None else t.zeros((X.shape[1], H), device=X.device)
         c = x[6][0] if len(x) > 6 and x[6] is not None else t.zeros((X.shape[1], H), device=X.device)
+        if X.is_cuda and X.shape[0] == 1 and X.dtype == t.float32:
+            # one step for all envs: the engine's fused cell (gates on the matrix pipe + activations, one launch)
+            out = self._lstm_cell_hip(X[0], h, c, W, R, Bv)
+            if out is not None:
+                hn, cn = out
+                return hn.unsqueeze(0).unsqueeze(1), hn.unsqueeze(0), cn.unsqueeze(0)
         bias = Bv[:4 * H] + Bv[4 * H:]
         ys = []
         for s in range(X.shape[0]):
@@ -255,6 +261,34 @@ class OnnxGraph:
             h = t.sigmoid(o) * t.tanh(c)
             ys.append(h)
         return t.stack(ys).unsqueeze(1), h.unsqueeze(0), c.unsqueeze(0)
+
+
+def _lstm_cell_hip(self, x, h, c, W, R, Bv):
+    """``cosim_lstm_cell`` (csrc/cosim_mlp.hip): None when the library is not available (the interpreter's own ops then run)."""
+    import ctypes
+    t = self.torch
+    if getattr(self, "_lstm_lib", None) is None:
+        try:
+            from .engine import load_library
+            L = load_library()
+            L.cosim_lstm_cell.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_int] * 3 + [ctypes.c_void_p] * 6
+            L.cosim_lstm_cell.restype = ctypes.c_int
+            L.cosim_last_error.restype = ctypes.c_char_p
+            self._lstm_lib = L
+        except Exception:  # noqa: BLE001
+            self._lstm_lib = False
+    if not self._lstm_lib:
+        return None
+    x, h, c, W, R, Bv = (a.contiguous() for a in (x, h, c, W, R, Bv))
+    hn, cn = t.empty_like(h), t.empty_like(c)
+    rc = self._lstm_lib.cosim_lstm_cell(x.data_ptr(), h.data_ptr(), c.data_ptr(), x.shape[0], x.shape[1], h.shape[1], W.data_ptr(), R.data_ptr(),
+                                        Bv.data_ptr(), hn.data_ptr(), cn.data_ptr(), t.cuda.current_stream(x.device).cuda_stream)
+    if rc != 0:
+        raise RuntimeError(self._lstm_lib.cosim_last_error().decode())
+    return hn, cn
+
+
+OnnxGraph._lstm_cell_hip = _lstm_cell_hip
 
 
 # ---------------------------------------------------------------------------------------------- the reference's classes, batched

@@ -140,6 +140,12 @@ int cosim_profile_step(cosim_engine_t* e, const float* actions_dev, const float*
 int cosim_mlp_forward(const float* x_dev, int n, int n_layers, const int* dims, const float* const* w_dev, const float* const* b_dev,
                       const int* act, const float* act_alpha, float clip, float* out_dev, void* stream);
 
+/* The recurrent policy's cell (reference core/policy.py:24-47: an ONNX LSTM node fed one step at a time with h_in / c_in kept by the
+ * caller): one LSTM step for all N envs in one launch.  Gate order and layouts are ONNX's: w_dev [4H, I], r_dev [4H, H], b_dev [8H]
+ * (Wb then Rb) or NULL, gates i, o, f, c; default activations.  h_out_dev / c_out_dev may alias h_dev / c_dev (in-place state). */
+int cosim_lstm_cell(const float* x_dev, const float* h_dev, const float* c_dev, int n, int in_dim, int hidden, const float* w_dev,
+                    const float* r_dev, const float* b_dev, float* h_out_dev, float* c_out_dev, void* stream);
+
 /* Reporter side (reference core/reporter.py:210-218 write_info, :429-442, :506-508): fleet statistics of one step's info in one
  * launch.  acc_dev is double[3][K], K = 4 + nu + ncmd <= 32: count, sum, sum of squares of info[:, 0:4], |info[:, 4:4+nu]| (torque)
  * and |cmd[:, i] - info[:, 1 + i]| for i < ncmd <= 3 (command tracking); cmd_dev is [N, cmd_stride]. */

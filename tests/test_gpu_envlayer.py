@@ -377,3 +377,47 @@ def test_step_range_shards_on_streams_equal_the_single_launch():
         b.engine.step_range(n - 8, 16, acts[0].data_ptr(), b._cmd_ptr(), b.state.data_ptr(), b.terminated.data_ptr(), b.truncated.data_ptr(),
                             b.info_buf.data_ptr(), None)
     a.close(); b.close()
+
+
+@pytest.mark.parametrize("I,H,n", [(52, 256, 4096), (88, 64, 333), (10, 6, 5)])
+def test_lstm_cell_kernel_matches_the_fp64_cell(tmp_path, I, H, n):
+    """N1: the recurrent policy (core/policy.py:24-47) with its LSTM node as ONE launch of cosim_lstm_cell (gates i, o, f, c on the
+    matrix pipe, activations fused), checked against the fp64 numpy cell over several steps with the state carried per env, plus the
+    masked state reset and the in-place state update a graph replay relies on."""
+    import torch
+    from cosim_amd.policy import LSTMPolicy, build_policy, write_onnx
+    rng = np.random.default_rng(1)
+    A = 4
+    W = (0.4 * rng.standard_normal((1, 4 * H, I)) / np.sqrt(I / 8)).astype(np.float32)
+    R = (0.4 * rng.standard_normal((1, 4 * H, H)) / np.sqrt(H / 8)).astype(np.float32)
+    B = (0.1 * rng.standard_normal((1, 8 * H))).astype(np.float32)
+    Wo = (0.5 * rng.standard_normal((A, H)) / np.sqrt(H / 8)).astype(np.float32)
+    bo = np.zeros(A, dtype=np.float32)
+    nodes = [{"op": "Unsqueeze", "inputs": ["obs"], "outputs": ["x3"], "attrs": {"axes": [0]}},
+             {"op": "LSTM", "inputs": ["x3", "W", "R", "B", "", "h_in", "c_in"], "outputs": ["Y", "h_out", "c_out"], "attrs": {"hidden_size": H}},
+             {"op": "Squeeze", "inputs": ["h_out"], "outputs": ["hs"], "attrs": {"axes": [0]}},
+             {"op": "Gemm", "inputs": ["hs", "Wo", "bo"], "outputs": ["actions"], "attrs": {"transB": 1}}]
+    p = str(tmp_path / "lstm.onnx")
+    write_onnx(p, nodes, {"W": W, "R": R, "B": B, "Wo": Wo, "bo": bo}, ["obs", "h_in", "c_in"], ["actions", "h_out", "c_out"])
+    pol = build_policy({"policy": {"use_lstm": True, "h_in_dim": H, "c_in_dim": H}}, p, num_envs=n, device="cuda:0")
+    assert isinstance(pol, LSTMPolicy)
+    hptr = pol.h_in.data_ptr()
+    sig = lambda v: 1 / (1 + np.exp(-v))
+    h = np.zeros((n, H)); c = np.zeros((n, H))
+    W64, R64, b64 = W[0].astype(np.float64), R[0].astype(np.float64), (B[0, :4 * H] + B[0, 4 * H:]).astype(np.float64)
+    for t in range(4):
+        x = rng.standard_normal((n, I)).astype(np.float32)
+        g = x.astype(np.float64) @ W64.T + h @ R64.T + b64
+        i, o, f, cc = g[:, :H], g[:, H:2 * H], g[:, 2 * H:3 * H], g[:, 3 * H:]
+        c = sig(f) * c + sig(i) * np.tanh(cc)
+        h = sig(o) * np.tanh(c)
+        got = pol.get_action(torch.tensor(x, device="cuda:0")).cpu().numpy()
+        np.testing.assert_allclose(got, np.clip(h @ Wo.T.astype(np.float64) + bo, -1, 1), atol=3e-5)
+        np.testing.assert_allclose(pol.h_in[0].cpu().numpy(), h, atol=2e-5)
+        np.testing.assert_allclose(pol.c_in[0].cpu().numpy(), c, atol=2e-5)
+    assert pol.h_in.data_ptr() == hptr                                # state updated in place (graph replay feeds it back)
+    assert pol.graph._lstm_lib not in (None, False)                   # the HIP cell ran, not the interpreter's op chain
+    mask = np.zeros(n, np.uint8); mask[::3] = 1
+    pol.reset(mask)
+    hh = pol.h_in[0].cpu().numpy()
+    assert np.abs(hh[::3]).max() == 0.0 and np.abs(hh[1::3]).max() > 0.0
