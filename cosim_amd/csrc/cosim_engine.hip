@@ -440,8 +440,14 @@ int cosim_create(const cosim_model_t* model, const float* hull_vert, const int* 
       e->ct_contact_slots = 32;
     }
   }
-  else if (nv == 14 && nb <= 10 && (gtm & ~G_MESH) == 0) select_t<14, 10, 2, G_MESH, true, 32, 64>(e, hf);   // flamingo_p_v3
-  else if (nv == 22 && nb <= 18 && (gtm & ~G_MESH) == 0) select_t<22, 18, 2, G_MESH, true, 128, 128>(e, hf);   // w4_p_v2
+  else if (nv == 14 && nb <= 10 && (gtm & ~G_MESH) == 0) {   // flamingo_p_v3
+    select_t<14, 10, 2, G_MESH, true, 32, 64>(e, hf);
+    if (!hf) e->launch_prof = launch_prof_t<14, 10, 2, false, G_MESH, true, 32>;
+  }
+  else if (nv == 22 && nb <= 18 && (gtm & ~G_MESH) == 0) {   // w4_p_v2
+    select_t<22, 18, 2, G_MESH, true, 128, 128>(e, hf);
+    if (hf) e->launch_prof = launch_prof_t<22, 18, 2, true, G_MESH, true, 128>;
+  }
   else if (nv == 29 && nb <= 26 && (gtm & ~G_HUM) == 0) {     // humanoid_p_v0
     select_t<29, 26, 2, G_HUM, true, 128, 256>(e, hf);
     if (hf) e->launch_prof = launch_prof_t<29, 26, 2, true, G_HUM, true, 256>;

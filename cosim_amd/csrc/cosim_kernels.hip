@@ -1345,6 +1345,8 @@ __global__ __launch_bounds__(64, (EPW == 2 ? 2 : (163840 / (int)sizeof(typename 
         }
       }
 
+      unsigned long long pc0_ = 0;
+      if (PROF) { __builtin_amdgcn_s_waitcnt(0); pc0_ = __builtin_amdgcn_s_memtime(); }
       if constexpr (SC) {
         // =========================================================== robot-robot pairs (mjc_Convex: one MPR contact per pair)
         // candidates: the compiled pair list (contype/conaffinity, same-body, parent-child and <exclude> filters applied)
@@ -1441,6 +1443,7 @@ __global__ __launch_bounds__(64, (EPW == 2 ? 2 : (163840 / (int)sizeof(typename 
         }
       }
 
+      if (PROF && !HF) { __builtin_amdgcn_s_waitcnt(0); pext[0] += __builtin_amdgcn_s_memtime() - pc0_; }   // flat kernels: [16] = robot-robot pairs (heightfield kernels use pext[0..2] for the prism walk; pairs = collision - those)
       STAMP(5);   // collision
       // =========================================================== constraint rows (lane = row)
       const int ne = 3 * dm.neq, nf = dm.nfric;

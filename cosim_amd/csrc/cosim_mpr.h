@@ -127,14 +127,32 @@ __device__ __forceinline__ bool mpr_reach_tol(const MprSup& p1, const MprSup& p2
   const real d = fmin(dv4 - mpr_dot(p1.v, dir), fmin(dv4 - mpr_dot(p2.v, dir), dv4 - mpr_dot(p3.v, dir)));
   return mpr_eq(d, MPR_TOL) || d < MPR_TOL;
 }
+// Portal vertices are replaced by predicated field-wise moves, never by `if (c) p1 = v4; else p3 = v4;`: the compiler merges such
+// stores into one store through a selected POINTER, which pins all the portal's support points in scratch memory for the whole
+// routine (measured: the MPR loops then ran at scratch latency, ~1000 cycles per iteration).
+__device__ __forceinline__ void sup_copy_if(MprSup& d, const MprSup& s, bool c) {
+#pragma unroll
+  for (int k = 0; k < 3; k++) { d.v[k] = c ? s.v[k] : d.v[k]; d.v1[k] = c ? s.v1[k] : d.v1[k]; }
+}
+__device__ __forceinline__ void sup_swap_if(MprSup& a, MprSup& b, bool c) {
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    const real t = c ? b.v[k] : a.v[k];
+    b.v[k] = c ? a.v[k] : b.v[k];
+    a.v[k] = t;
+    const float u = c ? b.v1[k] : a.v1[k];
+    b.v1[k] = c ? a.v1[k] : b.v1[k];
+    a.v1[k] = u;
+  }
+}
 __device__ __forceinline__ void mpr_expand(const real* v0, MprSup& p1, MprSup& p2, MprSup& p3, const MprSup& v4) {
   real v4v0[3];
   mpr_cross(v4v0, v4.v, v0);
-  if (mpr_dot(p1.v, v4v0) > 0.) {
-    if (mpr_dot(p2.v, v4v0) > 0.) p1 = v4; else p3 = v4;
-  } else {
-    if (mpr_dot(p3.v, v4v0) > 0.) p2 = v4; else p1 = v4;
-  }
+  const bool a = mpr_dot(p1.v, v4v0) > 0., b = mpr_dot(p2.v, v4v0) > 0., c = mpr_dot(p3.v, v4v0) > 0.;
+  // a: (b ? p1 : p3) = v4;  !a: (c ? p2 : p1) = v4
+  sup_copy_if(p1, v4, a ? b : !c);
+  sup_copy_if(p2, v4, !a && c);
+  sup_copy_if(p3, v4, a && !b);
 }
 __device__ __forceinline__ real mpr_seg_dist2(const real* x0, const real* b, real* wit) {   // ccdVec3PointSegmentDist2, P = origin
   const real d[3] = {b[0] - x0[0], b[1] - x0[1], b[2] - x0[2]};
@@ -218,9 +236,10 @@ __device__ __forceinline__ bool mpr_penetration(const SUP& sup, const float* c1,
   for (int k = 0; k < 3; k++) { va[k] = p1.v[k] - v0[k]; vb[k] = p2.v[k] - v0[k]; }
   mpr_cross(dir, va, vb);
   mpr_normalize(dir);
-  if (mpr_dot(dir, v0) > 0.) {
-    const MprSup t = p1; p1 = p2; p2 = t;
-    dir[0] = -dir[0]; dir[1] = -dir[1]; dir[2] = -dir[2];
+  {
+    const bool flip = mpr_dot(dir, v0) > 0.;
+    sup_swap_if(p1, p2, flip);
+    for (int k = 0; k < 3; k++) dir[k] = flip ? -dir[k] : dir[k];
   }
   {
     int it = 0;
@@ -229,16 +248,15 @@ __device__ __forceinline__ bool mpr_penetration(const SUP& sup, const float* c1,
       sup(dir, p3);
       dt = mpr_dot(p3.v, dir);
       if (mpr_zero(dt) || dt < 0.) return false;
-      bool cont = false;
       mpr_cross(va, p1.v, p3.v);
       dt = mpr_dot(va, v0);
-      if (dt < 0. && !mpr_zero(dt)) { p2 = p3; cont = true; }
-      if (!cont) {
-        mpr_cross(va, p3.v, p2.v);
-        dt = mpr_dot(va, v0);
-        if (dt < 0. && !mpr_zero(dt)) { p1 = p3; cont = true; }
-      }
-      if (!cont) break;
+      const bool ca = dt < 0. && !mpr_zero(dt);            // origin outside (v1, v0, v3): p2 = p3
+      mpr_cross(va, p3.v, p2.v);
+      dt = mpr_dot(va, v0);
+      const bool cb = !ca && dt < 0. && !mpr_zero(dt);     // else outside (v3, v0, v2): p1 = p3
+      sup_copy_if(p2, p3, ca);
+      sup_copy_if(p1, p3, cb);
+      if (!(ca || cb)) break;
       for (int k = 0; k < 3; k++) { va[k] = p1.v[k] - v0[k]; vb[k] = p2.v[k] - v0[k]; }
       mpr_cross(dir, va, vb);
       mpr_normalize(dir);
