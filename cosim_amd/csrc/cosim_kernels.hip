@@ -957,7 +957,7 @@ __global__ __launch_bounds__(64, (EPW == 2 ? 2 : (163840 / (int)sizeof(typename 
       const float4* const gext_ = A.gext;   // (locals, so that the lambdas below do not capture the argument-block pointer)
       const float* const hfdata_ = A.hfield;
       // world pose of geom g as a convex object (mesh: body frame, vertices in body coordinates; primitive: geom frame)
-      auto make_cobj = [&](CObj& o, int g) {
+      auto make_cobj = [&](CObj& o, int g) __attribute__((always_inline)) {
         const LaneRec& G = dm.rec[g];
         const int gb = G.g_body;
         const float bq[4] = {S.xquat[gb][0], S.xquat[gb][1], S.xquat[gb][2], S.xquat[gb][3]};
@@ -1116,7 +1116,7 @@ __global__ __launch_bounds__(64, (EPW == 2 ? 2 : (163840 / (int)sizeof(typename 
             if (PROF) pext[3] += total;
             // work item -> its geom, the geom's contact margin and the prism (strip vertices kk, kk + 1, kk + 2 of strip row r: vertex v
             // sits in column cmin + (v >> 1), row r + 1 for even v and r for odd v)
-            auto item_prism = [&](int item, int& g, float& gmargin, PrismObj& P) {
+            auto item_prism = [&](int item, int& g, float& gmargin, PrismObj& P) __attribute__((always_inline)) {
               while (item >= S.hf_end[g]) g++;
               const int k = item - (g > 0 ? S.hf_end[g > 0 ? g - 1 : 0] : 0), ppr = S.hf_ppr[g], rrow = k / ppr, kk = k - rrow * ppr;
               const int r = S.hf_rmin[g] + rrow, cmin = S.hf_cmin[g];
@@ -1130,12 +1130,12 @@ __global__ __launch_bounds__(64, (EPW == 2 ? 2 : (163840 / (int)sizeof(typename 
                 P.zt[i] = T.data[rr * T.ncol + c] * T.sz + T.gz + gmargin;
               }
             };
-            auto prism_centre = [](const PrismObj& P, float* c1) {
+            auto prism_centre = [](const PrismObj& P, float* c1) __attribute__((always_inline)) {
               c1[0] = (P.x[0] + P.x[1] + P.x[2]) * (1.f / 3.f); c1[1] = (P.y[0] + P.y[1] + P.y[2]) * (1.f / 3.f);
               c1[2] = (P.zt[0] + P.zt[1] + P.zt[2] + 3.f * P.zb) * (1.f / 6.f);
             };
             // full MPR on up to 64 listed items (one per lane, list order = (geom, strip) order) and ordered append of the hits
-            auto run_listed = [&](int cnt) {
+            auto run_listed = [&](int cnt) __attribute__((always_inline)) {
               bool hit = false;
               int g = 0;
               float depth = 0.f, nrm_[3] = {0.f, 0.f, 1.f}, pos_[3] = {0.f, 0.f, 0.f}, gmargin = 0.f;
@@ -1171,91 +1171,86 @@ __global__ __launch_bounds__(64, (EPW == 2 ? 2 : (163840 / (int)sizeof(typename 
               if (ln == 0) S.ncon_ctr += __popcll(km);
               WSYNC();
             };
-            // probe pass on up to 64 height-test survivors (one per lane, in order): MPR's first two exits decide most of them, the
-            // undecided ones go to the second list
-            int nlist = 0, nz = 0;
-            auto flush_full = [&](bool all) {
-              while (nlist >= 64 || (all && nlist > 0)) {
+            // Three stages, each on compacted batches of up to 64 items, one call site per stage (so that each inlines once):
+            //   height pass (all items): a prism whose top lies entirely below the geom's lowest point cannot touch it
+            //     (mjc_ConvexHField's own test) -- three loads and three compares per item; survivors -> zlist;
+            //   probe pass (zlist): MPR's first two exits decide most survivors; the undecided ones -> list;
+            //   full pass (list): MPR, ordered append of the hits.
+            // The later stage runs as soon as its list holds a full batch; the tails are drained at the end.
+            int nlist = 0, nz = 0, base = 0;
+            bool walked = total == 0;
+            while (!(walked && nz == 0 && nlist == 0)) {
+              if (nlist >= 64 || (walked && nz == 0)) {
                 const int cnt = min(nlist, 64);
                 if (PROF) { pext[6] += 1; pext[7] += cnt; }
                 run_listed(cnt);
-                PEXT_ADD(2);
                 const int moved = (ln + 64 < nlist) ? S.hf_list[ln + 64] : 0;
                 WSYNC();
                 if (ln + 64 < nlist) S.hf_list[ln] = moved;
                 nlist -= cnt;
                 WSYNC();
-              }
-            };
-            auto probe_listed = [&](int cnt) {
-              bool maybe = false;
-              int item = 0;
-              if (ln < cnt) {
-                item = S.hf_zlist[ln];
-                int g = 0;
-                float gmargin;
-                PrismObj P;
-                item_prism(item, g, gmargin, P);
-                if (S.hf_cnt[g] < 50) {
-                  CObj o;
-                  make_cobj(o, g);
-                  float c1[3];
-                  prism_centre(P, c1);
-                  const MprPrismGeom<GTM, false> sup{P, o, HG, ln};
-                  maybe = mpr_probe(sup, c1, o.center);
-                }
-              }
-              const unsigned long long mm_ = __ballot(maybe);
-              if (maybe) S.hf_list[nlist + __popcll(mm_ & lanemask_lt(ln))] = item;
-              nlist += __popcll(mm_);
-              WSYNC();
-              PEXT_ADD(1);
-              if (PROF) { pext[4] += 1; pext[5] += cnt; }
-              flush_full(false);
-            };
-            auto flush_probe = [&](bool all) {
-              while (nz >= 64 || (all && nz > 0)) {
+                PEXT_ADD(2);
+              } else if (nz >= 64 || walked) {
                 const int cnt = min(nz, 64);
-                probe_listed(cnt);
+                bool maybe = false;
+                int item = 0;
+                if (ln < cnt) {
+                  item = S.hf_zlist[ln];
+                  int g = 0;
+                  float gmargin;
+                  PrismObj P;
+                  item_prism(item, g, gmargin, P);
+                  if (S.hf_cnt[g] < 50) {
+                    CObj o;
+                    make_cobj(o, g);
+                    float c1[3];
+                    prism_centre(P, c1);
+                    const MprPrismGeom<GTM, false> sup{P, o, HG, ln};
+                    maybe = mpr_probe(sup, c1, o.center);
+                  }
+                }
                 const int moved = (ln + 64 < nz) ? S.hf_zlist[ln + 64] : 0;
+                const unsigned long long mm_ = __ballot(maybe);
+                if (maybe) S.hf_list[nlist + __popcll(mm_ & lanemask_lt(ln))] = item;
+                nlist += __popcll(mm_);
                 WSYNC();
                 if (ln + 64 < nz) S.hf_zlist[ln] = moved;
                 nz -= cnt;
                 WSYNC();
-              }
-            };
-            int base = 0;
-            while (base < total) {
-              int g0 = 0;
-              while (base >= __builtin_amdgcn_readfirstlane(S.hf_end[g0])) g0++;   // uniform; terminates: base < total = hf_end[23]
-              if (__builtin_amdgcn_readfirstlane(S.hf_cnt[g0]) >= 50) { base = __builtin_amdgcn_readfirstlane(S.hf_end[g0]); continue; }   // this geom has its 50 contacts: skip the rest of its prisms
-              // height pass: 64 items; a prism whose top lies entirely below the geom's lowest point cannot touch it (mjc_ConvexHField's
-              // own test) -- three loads and three compares per item, the survivors are listed in order
-              const int item = base + ln;
-              bool alive = false;
-              if (item < total) {
-                int g = g0;
-                while (item >= S.hf_end[g]) g++;
-                const int k = item - (g > 0 ? S.hf_end[g > 0 ? g - 1 : 0] : 0), ppr = S.hf_ppr[g], rrow = k / ppr, kk = k - rrow * ppr;
-                const int r = S.hf_rmin[g] + rrow, cmin = S.hf_cmin[g];
-                const float lo2 = S.hf_lo[g], add = T.gz + S.hf_mg[g];
-                bool below = true;
+                PEXT_ADD(1);
+                if (PROF) { pext[4] += 1; pext[5] += cnt; }
+              } else {
+                int g0 = 0;
+                while (base >= __builtin_amdgcn_readfirstlane(S.hf_end[g0])) g0++;   // uniform; terminates: base < total = hf_end[23]
+                if (__builtin_amdgcn_readfirstlane(S.hf_cnt[g0]) >= 50) {   // this geom has its 50 contacts: skip the rest of its prisms
+                  base = __builtin_amdgcn_readfirstlane(S.hf_end[g0]);
+                } else {
+                  const int item = base + ln;
+                  bool alive = false;
+                  if (item < total) {
+                    int g = g0;
+                    while (item >= S.hf_end[g]) g++;
+                    const int k = item - (g > 0 ? S.hf_end[g > 0 ? g - 1 : 0] : 0), ppr = S.hf_ppr[g], rrow = k / ppr, kk = k - rrow * ppr;
+                    const int r = S.hf_rmin[g] + rrow, cmin = S.hf_cmin[g];
+                    const float lo2 = S.hf_lo[g], add = T.gz + S.hf_mg[g];
+                    bool below = true;
 #pragma unroll
-                for (int i = 0; i < 3; i++) {
-                  const int v = kk + i, c = cmin + (v >> 1), rr = r + 1 - (v & 1);
-                  below = below && (T.data[rr * T.ncol + c] * T.sz + add < lo2);
+                    for (int i = 0; i < 3; i++) {
+                      const int v = kk + i, c = cmin + (v >> 1), rr = r + 1 - (v & 1);
+                      below = below && (T.data[rr * T.ncol + c] * T.sz + add < lo2);
+                    }
+                    alive = !below && S.hf_cnt[g] < 50;
+                  }
+                  const unsigned long long am = __ballot(alive);
+                  if (alive) S.hf_zlist[nz + __popcll(am & lanemask_lt(ln))] = item;
+                  nz += __popcll(am);
+                  base += 64;
+                  WSYNC();
                 }
-                alive = !below && S.hf_cnt[g] < 50;
+                walked = base >= total;
+                PEXT_ADD(0);
               }
-              const unsigned long long am = __ballot(alive);
-              if (alive) S.hf_zlist[nz + __popcll(am & lanemask_lt(ln))] = item;
-              nz += __popcll(am);
-              base += 64;
-              WSYNC();
-              flush_probe(false);
             }
-            flush_probe(true);
-            flush_full(true);
             ncon = S.ncon_ctr;
             // hulls with few prisms: wave-cooperative, one (geom, prism) at a time (hfield_geom: the same walk, sequential)
             for (unsigned long long cm_ = __ballot(coop_geom); cm_; cm_ &= cm_ - 1) {
