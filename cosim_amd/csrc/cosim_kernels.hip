@@ -1113,7 +1113,7 @@ __global__ __launch_bounds__(64, (EPW == 2 ? 2 : (163840 / (int)sizeof(typename 
             const int total = __builtin_amdgcn_readlane(end, 23);   // lanes past ngeom add nothing
             WSYNC();
             PEXT_ADD(0);
-            if (PROF) pext[3] += total;
+
             // work item -> its geom, the geom's contact margin and the prism (strip vertices kk, kk + 1, kk + 2 of strip row r: vertex v
             // sits in column cmin + (v >> 1), row r + 1 for even v and r for odd v)
             auto item_prism = [&](int item, int& g, float& gmargin, PrismObj& P) __attribute__((always_inline)) {
@@ -1137,8 +1137,11 @@ __global__ __launch_bounds__(64, (EPW == 2 ? 2 : (163840 / (int)sizeof(typename 
             // full MPR on up to 64 listed items (one per lane, list order = (geom, strip) order) and ordered append of the hits
             auto run_listed = [&](int cnt) __attribute__((always_inline)) {
               bool hit = false;
+              int mpr_iters = 0;
               int g = 0;
               float depth = 0.f, nrm_[3] = {0.f, 0.f, 1.f}, pos_[3] = {0.f, 0.f, 0.f}, gmargin = 0.f;
+              unsigned long long tq0 = 0, tq1 = 0;
+              if (PROF) { __builtin_amdgcn_s_waitcnt(0); tq0 = __builtin_amdgcn_s_memtime(); }
               if (ln < cnt) {
                 PrismObj P;
                 item_prism(S.hf_list[ln], g, gmargin, P);
@@ -1147,9 +1150,23 @@ __global__ __launch_bounds__(64, (EPW == 2 ? 2 : (163840 / (int)sizeof(typename 
                   make_cobj(o, g);
                   float c1[3];
                   prism_centre(P, c1);
+                  if (PROF) { __builtin_amdgcn_s_waitcnt(0); tq1 = __builtin_amdgcn_s_memtime(); }
                   const MprPrismGeom<GTM, false> sup{P, o, HG, ln};
-                  hit = mpr_penetration(sup, c1, o.center, depth, nrm_, pos_) && (nrm_[0] != 0.f || nrm_[1] != 0.f || nrm_[2] != 0.f);
+                  int nit = 0;
+                  hit = mpr_penetration(sup, c1, o.center, depth, nrm_, pos_, PROF ? &nit : nullptr) && (nrm_[0] != 0.f || nrm_[1] != 0.f || nrm_[2] != 0.f);
+                  if (PROF) mpr_iters = nit;
                 }
+              }
+              if (PROF) {   // [3] is reused in this build: sum over batches of the slowest lane's MPR loop iterations
+                __builtin_amdgcn_s_waitcnt(0);
+                const unsigned long long tq2 = __builtin_amdgcn_s_memtime();
+                const unsigned long long am_ = __ballot(tq1 != 0);   // tq1 was taken inside the divergent branch: read it from a lane that ran
+                const unsigned t1 = am_ ? (unsigned)__builtin_amdgcn_readlane((int)(unsigned)tq1, __builtin_ctzll(am_)) : (unsigned)tq0;
+                pext[5] += (unsigned)((unsigned)tq2 - t1);            // diagnostic: cycles inside mpr_penetration ...
+                pext[7] += (unsigned)(t1 - (unsigned)tq0);            // ... and in the item / geom set-up before it
+                int mx = mpr_iters;
+                for (int o_ = 32; o_ > 0; o_ >>= 1) mx = max(mx, __shfl_xor(mx, o_, 64));
+                pext[3] += mx;
               }
               int rank_g = 0;   // rank of a hit among the hits of its own geom
               for (unsigned long long rest = __ballot(hit); rest;) {
@@ -1182,7 +1199,7 @@ __global__ __launch_bounds__(64, (EPW == 2 ? 2 : (163840 / (int)sizeof(typename 
             while (!(walked && nz == 0 && nlist == 0)) {
               if (nlist >= 64 || (walked && nz == 0)) {
                 const int cnt = min(nlist, 64);
-                if (PROF) { pext[6] += 1; pext[7] += cnt; }
+                if (PROF) { pext[6] += 1; }
                 run_listed(cnt);
                 const int moved = (ln + 64 < nlist) ? S.hf_list[ln + 64] : 0;
                 WSYNC();
@@ -1218,7 +1235,7 @@ __global__ __launch_bounds__(64, (EPW == 2 ? 2 : (163840 / (int)sizeof(typename 
                 nz -= cnt;
                 WSYNC();
                 PEXT_ADD(1);
-                if (PROF) { pext[4] += 1; pext[5] += cnt; }
+                if (PROF) { pext[4] += 1; }
               } else {
                 int g0 = 0;
                 while (base >= __builtin_amdgcn_readfirstlane(S.hf_end[g0])) g0++;   // uniform; terminates: base < total = hf_end[23]
@@ -1396,10 +1413,25 @@ __global__ __launch_bounds__(64, (EPW == 2 ? 2 : (163840 / (int)sizeof(typename 
                 if (fabsf(dot3(dv, a1)) > G1.g_half[k] + radius(m2, G2.g_half, a1) + mg) cand = false;
                 if (fabsf(dot3(dv, a2)) > G2.g_half[k] + radius(m1, G1.g_half, a2) + mg) cand = false;
               }
+              // ... and the nine edge x edge axes (the full box-box separating-axis test): a pair that survives costs the whole wave an
+              // MPR run over up to 700-vertex hulls, a rejected one costs this lane a few dozen FMAs
+              if (cand) {
+#pragma unroll
+                for (int i = 0; i < 3; i++) {
+                  const float a1[3] = {m1[i], m1[3 + i], m1[6 + i]};
+#pragma unroll
+                  for (int j = 0; j < 3; j++) {
+                    const float a2[3] = {m2[j], m2[3 + j], m2[6 + j]};
+                    float ax[3];
+                    cross(ax, a1, a2);
+                    const float n2 = dot3(ax, ax);
+                    if (n2 > 1e-8f && fabsf(dot3(dv, ax)) > radius(m1, G1.g_half, ax) + radius(m2, G2.g_half, ax) + mg * sqrtf(n2)) cand = false;
+                  }
+                }
+              }
             }
-            // pairs with a convex hull: lane-parallel too (each lane climbs the hull's neighbour graph) unless the engine was told to
-            // run them one at a time with all 64 lanes sharing the vertex scans (cosim_set_param "pair_mode" 1; the two differ only
-            // in which of several equally extreme vertices a support query returns)
+            // pairs with a convex hull: one at a time with all 64 lanes sharing the vertex scans (cosim_set_param "pair_mode" 0 runs them
+            // lane-parallel, every lane scanning its own hulls: measured slower on the 700-vertex wheel hulls)
             mesh = cand && A.pair_coop && (G1.g_type == CS_GEOM_MESH || G2.g_type == CS_GEOM_MESH);
           }
           bool hit = false;

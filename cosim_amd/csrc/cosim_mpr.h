@@ -61,18 +61,33 @@ __device__ __forceinline__ void cobj_support(const CObj& o, const HullGraph& H, 
   float l[3], r[3] = {0.f, 0.f, 0.f};
   qrot(l, qi, dir);
   if (!COOP && (GTM & GT_MESH) && o.kind == CS_GEOM_MESH) {
-    // every lane scans the whole hull for its own direction.  Lanes that work on the same geom walk the same addresses, so the
-    // loads are broadcasts; the first maximum wins (lowest index among ties, like a sequential scan and like the COOP path).
+    // every lane scans the whole hull for its own direction; the first maximum wins (lowest index among ties, like a sequential
+    // scan and like the COOP path).  The lanes of a batch hold at most a few different hulls: they are served one hull at a time
+    // with a wave-uniform base (readfirstlane), so the vertex loads are uniform-address loads, and four vertices are in flight per
+    // trip (a dependent load per vertex made this loop cost ~600 cycles per vertex).
     // (Hill climbing on the neighbour graph from a direction-indexed seed was measured 2x slower here: its dependent,
     // lane-divergent loads do not overlap.)
     float best = -3.0e38f;
     int bi = 0;
-    const float* v0 = hull + 3 * o.adr;
-    for (int i = 0; i < o.num; i++) {
-      const float t = l[0] * v0[3 * i] + l[1] * v0[3 * i + 1] + l[2] * v0[3 * i + 2];
-      if (t > best) { best = t; bi = i; }
+    bool pending = true;
+    for (unsigned long long pm = __ballot(pending); pm != 0ull; pm = __ballot(pending)) {
+      const int src = __builtin_ctzll(pm);   // a lane that still waits: its hull is served now
+      const int adr_u = __builtin_amdgcn_readlane(o.adr, src), num_u = __builtin_amdgcn_readlane(o.num, src);
+      const bool mine = pending && o.adr == adr_u;
+      const float* v0 = hull + 3 * (size_t)adr_u;
+      for (int i = 0; i < num_u; i += 4) {
+        float x[12];
+#pragma unroll
+        for (int k = 0; k < 12; k++) x[k] = v0[min(3 * i + k, 3 * num_u - 1)];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          const float t = l[0] * x[3 * k] + l[1] * x[3 * k + 1] + l[2] * x[3 * k + 2];
+          if (mine && i + k < num_u && t > best) { best = t; bi = i + k; }
+        }
+      }
+      if (mine) pending = false;
     }
-    const float* v = v0 + 3 * bi;
+    const float* v = hull + 3 * (o.adr + bi);
     r[0] = v[0]; r[1] = v[1]; r[2] = v[2];
   } else if (COOP && (GTM & GT_MESH) && o.kind == CS_GEOM_MESH) {
     float best = -3.0e38f;
@@ -206,7 +221,8 @@ __device__ __forceinline__ bool mpr_probe(const SUP& sup, const float* c1, const
 
 // ccdMPRPenetration: true when the geoms penetrate; depth, dir (geom1 -> geom2) and pos as libccd returns them.
 template <class SUP>
-__device__ __forceinline__ bool mpr_penetration(const SUP& sup, const float* c1, const float* c2, float& depth_out, float* dir_f, float* pos_f) {
+__device__ __forceinline__ bool mpr_penetration(const SUP& sup, const float* c1, const float* c2, float& depth_out, float* dir_f, float* pos_f,
+                                                int* n_iter = nullptr) {   // n_iter: diagnostic builds count loop iterations
   MprSup p1, p2, p3, v4;
   real depth, dir_out[3], pos[3];
   real v0[3] = {(real)c1[0] - (real)c2[0], (real)c1[1] - (real)c2[1], (real)c1[2] - (real)c2[2]};
@@ -245,6 +261,7 @@ __device__ __forceinline__ bool mpr_penetration(const SUP& sup, const float* c1,
     int it = 0;
     for (;;) {
       if (++it > MPR_MAXIT) return false;
+      if (n_iter) ++*n_iter;
       sup(dir, p3);
       dt = mpr_dot(p3.v, dir);
       if (mpr_zero(dt) || dt < 0.) return false;
@@ -267,6 +284,7 @@ __device__ __forceinline__ bool mpr_penetration(const SUP& sup, const float* c1,
     int it = 0;
     for (;;) {
       if (++it > MPR_MAXIT) return false;
+      if (n_iter) ++*n_iter;
       mpr_portal_dir(p1, p2, p3, dir);
       dt = mpr_dot(dir, p1.v);
       if (mpr_zero(dt) || dt > 0.) break;               // portalEncapsulesOrigin
@@ -285,6 +303,7 @@ __device__ __forceinline__ bool mpr_penetration(const SUP& sup, const float* c1,
       if (mpr_reach_tol(p1, p2, p3, v4, dir) || it > MPR_MAXIT) break;
       mpr_expand(v0, p1, p2, p3, v4);
       it++;
+      if (n_iter) ++*n_iter;
     }
   }
   real pd[3];

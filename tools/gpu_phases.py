@@ -42,8 +42,8 @@ for i in list(range(10)) + [10, 11, 12, 13, 14, 15]:
 if acc[19] > 0:
     print(f"  (robot-robot pairs = collision - prism walk: {acc[5]-acc[16]-acc[17]-acc[18]:.0f} cycles per step)")
     sub = int(env.cm.blob.frame_skip)
-    print(f"  heightfield narrowphase per substep: {acc[19]/sub:.0f} work items, {acc[20]/sub:.1f} probe batches ({acc[21]/sub:.0f} probes run), "
-          f"{acc[22]/sub:.1f} full-MPR batches ({acc[23]/sub:.0f} MPRs run); cycles: sub-grids {acc[16]/sub:.0f}, probe passes {acc[17]/sub:.0f}, "
+    print(f"  heightfield narrowphase per substep: slowest-lane MPR iterations summed over full batches {acc[19]/sub:.0f}, {acc[20]/sub:.1f} probe batches, "
+          f"{acc[22]/sub:.1f} full-MPR batches (inside mpr_penetration {acc[21]/sub:.0f} cycles, set-up before it {acc[23]/sub:.0f}); cycles: sub-grids {acc[16]/sub:.0f}, probe passes {acc[17]/sub:.0f}, "
           f"full batches {acc[18]/sub:.0f}")
 elif acc[16] > 0:
     print(f"  robot-robot pairs (broadphase + MPR): {acc[16]:.0f} cycles = {100*acc[16]/tot:.1f} % of the step")
