@@ -64,6 +64,7 @@ struct cosim_engine {
   int ct_lds_bytes = 0, ct_contact_slots = 0;
   int epw = 1;   // environments per wave of the reset / step launches
   int lds_bytes = 0;
+  int geom_stage = 64;   // plane kernels: geom lanes that can stage their contacts
   int contact_slots = 0, pair_slots = 0;   // ground-contact / robot-robot contact capacity of the selected kernel
 };
 
@@ -92,6 +93,7 @@ static void select_t(cosim_engine* e, bool hf) {
   e->lds_bytes = hf ? (int)sizeof(LH) : (int)sizeof(LF);
   e->contact_slots = hf ? LH::MC : LF::MC;
   e->pair_slots = hf ? LH::MCP : LF::MCP;
+  e->geom_stage = hf ? 64 : LF::NGS;
 }
 
 static int round_up(int x, int m) { return (x + m - 1) / m * m; }
@@ -453,6 +455,7 @@ int cosim_create(const cosim_model_t* model, const float* hull_vert, const int* 
     if (hf) e->launch_prof = launch_prof_t<29, 26, 2, true, G_HUM, true, 256>;
   }
   else { delete e; return fail(COSIM_EINVAL, "cosim_create: no kernel instantiation for this (nv, nbody); add one in cosim_engine.hip"); }
+  if (model->ngeom > e->geom_stage) { delete e; return fail(COSIM_EINVAL, "cosim_create: more collision geoms than the plane kernel stages contacts for"); }
   HIP_TRY(hipMalloc(&e->d_model, sizeof(DevModel)));
   HIP_TRY(hipMalloc(&e->d_obs, sizeof(DevObs)));
   HIP_TRY(hipMemcpy(e->d_model, &e->hm, sizeof(DevModel), hipMemcpyHostToDevice));

@@ -255,6 +255,7 @@ struct EnvLds : CtLds<(MCT > 0), HFL, NB, (MCT > 0 ? MCT : 1), (MCPT > 0 ? MCPT 
     float cin[NB][10];         // dead after the bias forces
     struct { float rowf[ROWS], rowD[ROWS]; } r;
   } w;
+  static constexpr int NGS = (int)(sizeof(u) / 64) < 24 ? (int)(sizeof(u) / 64) : 24;   // geom lanes that can stage plane contacts (4 x {dist, pos}) in u's space
   float J[NGEN][LD];
   float cpos[MC][3], cnrm[NRM ? MC : 1][3], cdist[MC];   // contact normals are +z on the plane: not stored
   int cgeom[MC];   // geom2 | (geom1 + 1) << 8; geom1 + 1 == 0: the ground
@@ -369,35 +370,30 @@ __device__ __forceinline__ void chol_park(float (*Lm)[LD], const float (&a)[NV],
 
 // ------------------------------------------------------------------------------------------------ geometry helpers
 // Contacts of one primitive geom (sphere / cylinder / box) against the plane through P0 with unit normal n:
-// mjc_PlaneSphere / mjc_PlaneCylinder / mjc_PlaneBox (engine_collision_primitive.c), split in two steps so that nothing is
-// ever indexed dynamically (a dynamically indexed local array lives in scratch memory) and little is live at once:
-//   prim_plane_mask  -> which of the (at most four) candidate points touch, plus the few vectors they are built from;
-//   prim_plane_point -> candidate j (compile-time j) as {dist, position}.
-// The j-th contact of the geom is the j-th set bit of the mask, in MuJoCo's order.
+// mjc_PlaneSphere / mjc_PlaneCylinder / mjc_PlaneBox (engine_collision_primitive.c).  The (at most four) contacts go, in
+// MuJoCo's order, to a staging area as {dist, x, y, z}; the count is returned.  Staging in LDS (the caller passes a region that is
+// dead during collision) instead of keeping the candidates' building blocks in registers across the slot assignment: a context
+// struct with the union of the three types' vectors spilled to scratch on both sides of the ballots.
 // GTM: geom types present in the model (bit 0 sphere, 1 cylinder, 2 box, 3 mesh): absent types cost no registers.
 constexpr int GT_SPHERE = 1, GT_CYLINDER = 2, GT_BOX = 4, GT_MESH = 8;
-struct PrimCtx {
-  float pos[3], a[3], b[3], c[3];  // geom centre; cylinder: half axis, rim vector, 120-degree rim vector; box: mat rows via a, b, c
-  float dist0, d[4];
-  unsigned mask;                   // cylinder / sphere: candidate bits; box: low 8 bits = touching corners
-  int gt;
-};
 template <int GTM>
-__device__ __forceinline__ void prim_plane_mask(const LaneRec& R, const float* xq, const float* xp, const float* P0, const float* n,
-                                                float margin, PrimCtx& cx) {
-  cx.mask = 0u;
-  cx.gt = R.g_type;
-  float v[3], gq[4], mat[9];
+__device__ __forceinline__ int prim_plane_contacts(const LaneRec& R, const float* xq, const float* xp, const float* P0, const float* n,
+                                                   float margin, float (*stage)[4]) {
+  const int gt = R.g_type;
+  float v[3], pos[3];
   qrot(v, xq, R.g_pos);
-  for (int k = 0; k < 3; k++) { cx.pos[k] = xp[k] + v[k]; cx.a[k] = 0.f; cx.b[k] = 0.f; cx.c[k] = 0.f; }
-  for (int k = 0; k < 4; k++) cx.d[k] = 0.f;
-  const float dist0 = n[0] * (cx.pos[0] - P0[0]) + n[1] * (cx.pos[1] - P0[1]) + n[2] * (cx.pos[2] - P0[2]);
-  cx.dist0 = dist0;
-  if ((GTM & GT_SPHERE) && cx.gt == CS_GEOM_SPHERE) {
-    const float r = R.g_size[0];
-    cx.d[0] = dist0 - r;
-    cx.mask = dist0 <= margin + r ? 1u : 0u;
-  } else if ((GTM & GT_CYLINDER) && cx.gt == CS_GEOM_CYLINDER) {
+  for (int k = 0; k < 3; k++) pos[k] = xp[k] + v[k];
+  const float dist0 = n[0] * (pos[0] - P0[0]) + n[1] * (pos[1] - P0[1]) + n[2] * (pos[2] - P0[2]);
+  int cnt = 0;
+  auto put = [&](float dist, float px, float py, float pz) {
+    stage[cnt][0] = dist; stage[cnt][1] = px; stage[cnt][2] = py; stage[cnt][3] = pz;
+    cnt++;
+  };
+  if ((GTM & GT_SPHERE) && gt == CS_GEOM_SPHERE) {
+    const float r = R.g_size[0], dist = dist0 - r;
+    if (dist0 <= margin + r) { const float a = r + 0.5f * dist; put(dist, pos[0] - n[0] * a, pos[1] - n[1] * a, pos[2] - n[2] * a); }
+  } else if ((GTM & GT_CYLINDER) && gt == CS_GEOM_CYLINDER) {
+    float gq[4], mat[9];
     qmul(gq, xq, R.g_quat);
     q2m(mat, gq);
     const float radius = R.g_size[0], half = R.g_size[1];
@@ -417,51 +413,38 @@ __device__ __forceinline__ void prim_plane_mask(const LaneRec& R, const float* x
     vec1[0] *= s1; vec1[1] *= s1; vec1[2] *= s1;
     const float prjvec1 = dot3(vec1, n);
     // candidate 0: deepest rim point of the near disk; 1: same rim point of the far disk; 2, 3: +-120 degrees on the near disk
-    cx.d[0] = dist0 + prjaxis + prjvec;
-    cx.d[1] = dist0 - prjaxis + prjvec;
-    cx.d[2] = dist0 + prjaxis - prjvec * 0.5f + prjvec1;
-    cx.d[3] = dist0 + prjaxis - prjvec * 0.5f - prjvec1;
-    for (int k = 0; k < 3; k++) { cx.a[k] = axis[k]; cx.b[k] = vec[k]; cx.c[k] = vec1[k]; }
-    const bool first = cx.d[0] <= margin;  // nothing can touch unless the deepest point does
-    cx.mask = first ? (1u | (cx.d[1] <= margin ? 2u : 0u) | (cx.d[2] <= margin ? 4u : 0u) | (cx.d[3] <= margin ? 8u : 0u)) : 0u;
-  } else if ((GTM & GT_BOX) && cx.gt == CS_GEOM_BOX) {
+    const float d0 = dist0 + prjaxis + prjvec, d1 = dist0 - prjaxis + prjvec, d2 = dist0 + prjaxis - prjvec * 0.5f + prjvec1,
+                d3 = dist0 + prjaxis - prjvec * 0.5f - prjvec1;
+    if (d0 <= margin) {   // nothing can touch unless the deepest point does
+      put(d0, pos[0] + axis[0] + vec[0] - n[0] * d0 * 0.5f, pos[1] + axis[1] + vec[1] - n[1] * d0 * 0.5f, pos[2] + axis[2] + vec[2] - n[2] * d0 * 0.5f);
+      if (d1 <= margin)
+        put(d1, pos[0] - axis[0] + vec[0] - n[0] * d1 * 0.5f, pos[1] - axis[1] + vec[1] - n[1] * d1 * 0.5f, pos[2] - axis[2] + vec[2] - n[2] * d1 * 0.5f);
+      if (d2 <= margin)
+        put(d2, pos[0] + axis[0] - 0.5f * vec[0] + vec1[0] - n[0] * d2 * 0.5f, pos[1] + axis[1] - 0.5f * vec[1] + vec1[1] - n[1] * d2 * 0.5f,
+            pos[2] + axis[2] - 0.5f * vec[2] + vec1[2] - n[2] * d2 * 0.5f);
+      if (d3 <= margin)
+        put(d3, pos[0] + axis[0] - 0.5f * vec[0] - vec1[0] - n[0] * d3 * 0.5f, pos[1] + axis[1] - 0.5f * vec[1] - vec1[1] - n[1] * d3 * 0.5f,
+            pos[2] + axis[2] - 0.5f * vec[2] - vec1[2] - n[2] * d3 * 0.5f);
+    }
+  } else if ((GTM & GT_BOX) && gt == CS_GEOM_BOX) {
+    float gq[4], mat[9], a[3], b[3], c[3];
     qmul(gq, xq, R.g_quat);
     q2m(mat, gq);
-    // corner i = sum_k (+-size_k) * column k of mat; keep n . column_k * size_k and the scaled columns
-    for (int k = 0; k < 3; k++) { cx.a[k] = mat[3 * k] * R.g_size[0]; cx.b[k] = mat[3 * k + 1] * R.g_size[1]; cx.c[k] = mat[3 * k + 2] * R.g_size[2]; }
-    const float na = dot3(n, cx.a), nb = dot3(n, cx.b), nc = dot3(n, cx.c);
-    unsigned m8 = 0u;
+    // corner i = sum_k (+-size_k) * column k of mat
+    for (int k = 0; k < 3; k++) { a[k] = mat[3 * k] * R.g_size[0]; b[k] = mat[3 * k + 1] * R.g_size[1]; c[k] = mat[3 * k + 2] * R.g_size[2]; }
+    const float na = dot3(n, a), nb = dot3(n, b), nc = dot3(n, c);
 #pragma unroll
-    for (int i = 0; i < 8; i++) {
-      const float ld = ((i & 1) ? na : -na) + ((i & 2) ? nb : -nb) + ((i & 4) ? nc : -nc);
-      if (!(dist0 + ld > margin || ld > 0.f)) m8 |= 1u << i;
+    for (int i = 0; i < 8; i++) {   // at most the first four touching corners, in corner-index order (mjc_PlaneBox)
+      const float s0 = (i & 1) ? 1.f : -1.f, s1 = (i & 2) ? 1.f : -1.f, s2 = (i & 4) ? 1.f : -1.f;
+      const float ld = s0 * na + s1 * nb + s2 * nc;
+      if (!(dist0 + ld > margin || ld > 0.f) && cnt < 4) {
+        const float dist = dist0 + ld;
+        put(dist, pos[0] + s0 * a[0] + s1 * b[0] + s2 * c[0] - n[0] * dist * 0.5f, pos[1] + s0 * a[1] + s1 * b[1] + s2 * c[1] - n[1] * dist * 0.5f,
+            pos[2] + s0 * a[2] + s1 * b[2] + s2 * c[2] - n[2] * dist * 0.5f);
+      }
     }
-    // at most the first four touching corners, in corner-index order (mjc_PlaneBox)
-    unsigned keep = 0u, rest = m8;
-#pragma unroll
-    for (int j = 0; j < 4; j++)
-      if (rest) { keep |= rest & (0u - rest); rest &= rest - 1; }
-    cx.mask = keep;   // corner bits (0..255); contact j = j-th set bit
-    cx.d[0] = na; cx.d[1] = nb; cx.d[2] = nc;
   }
-}
-// number of contacts, and the candidate index of the j-th contact's bit (identity for sphere / cylinder)
-__device__ __forceinline__ int prim_count(const PrimCtx& cx) { return __popc(cx.mask); }
-// candidate `bit` (a set bit position of cx.mask) as {dist, pos}
-__device__ __forceinline__ void prim_plane_point(const PrimCtx& cx, const float* n, int bit, float& dist, float* p) {
-  if (cx.gt == CS_GEOM_SPHERE) {
-    dist = cx.d[0];
-    const float a = (cx.dist0 - dist) + 0.5f * dist;  // r + dist / 2
-    for (int k = 0; k < 3; k++) p[k] = cx.pos[k] - n[k] * a;
-  } else if (cx.gt == CS_GEOM_CYLINDER) {
-    dist = bit == 0 ? cx.d[0] : (bit == 1 ? cx.d[1] : (bit == 2 ? cx.d[2] : cx.d[3]));
-    const float sa = bit == 1 ? -1.f : 1.f, sb = bit < 2 ? 1.f : -0.5f, sc = bit == 2 ? 1.f : (bit == 3 ? -1.f : 0.f);
-    for (int k = 0; k < 3; k++) p[k] = cx.pos[k] + sa * cx.a[k] + sb * cx.b[k] + sc * cx.c[k] - n[k] * dist * 0.5f;
-  } else {  // box corner `bit`
-    const float s0 = (bit & 1) ? 1.f : -1.f, s1 = (bit & 2) ? 1.f : -1.f, s2 = (bit & 4) ? 1.f : -1.f;
-    dist = cx.dist0 + s0 * cx.d[0] + s1 * cx.d[1] + s2 * cx.d[2];
-    for (int k = 0; k < 3; k++) p[k] = cx.pos[k] + s0 * cx.a[k] + s1 * cx.b[k] + s2 * cx.c[k] - n[k] * dist * 0.5f;
-  }
+  return cnt;
 }
 
 struct Terrain {  // heightfield geometry; (ox, oy) = world position of the local frame origin (the base's x, y)
@@ -1000,17 +983,21 @@ __global__ __launch_bounds__(64, (EPW == 2 ? 2 : (163840 / (int)sizeof(typename 
         const float margin = R.g_margin, rb = R.g_rbound;
         if (is_plane) {
           const float nz[3] = {0.f, 0.f, 1.f};
-          PrimCtx cx;
-          cx.mask = 0u;
+          // staging: the Hessian's LDS space, dead until the solver (16 floats per geom lane)
+          float (*stage)[4] = reinterpret_cast<float (*)[4]>(&S.u.H[0][0]) + 4 * (ln < L::NGS ? ln : 0);   // (cosim_create checks ngeom <= NGS)
+          int cnt = 0;
           if (active && gt == CS_GEOM_MESH) {
             // exact reject: lowest corner of the hull's body-frame box (oriented into the world) above the plane
             float m[9];
             q2m(m, xq);
             const float low = ctr[2] - T.gz - (fabsf(m[6]) * R.g_half[0] + fabsf(m[7]) * R.g_half[1] + fabsf(m[8]) * R.g_half[2]);
             mesh_near = low <= margin;
-          } else if (active) prim_plane_mask<GTM>(R, xq, xp, gpos, nz, margin, cx);
+          } else if (active) {
+            if constexpr ((GTM & ~GT_MESH) != 0) {
+              if (ln < L::NGS) cnt = prim_plane_contacts<GTM>(R, xq, xp, gpos, nz, margin, stage);
+            }
+          }
           // compaction in (geom, contact) order: slot = contacts of lower lanes + rank inside this geom
-          const int cnt = prim_count(cx);
           int off = 0, total = 0;
 #pragma unroll
           for (int s2 = 0; s2 < 4; s2++) {
@@ -1018,22 +1005,15 @@ __global__ __launch_bounds__(64, (EPW == 2 ? 2 : (163840 / (int)sizeof(typename 
             off += __popcll(mk & lanemask_lt(ln));
             total += __popcll(mk);
           }
-          {
-            unsigned rest = cx.mask;
+          if constexpr ((GTM & ~GT_MESH) != 0) {
 #pragma unroll
             for (int j = 0; j < 4; j++) {
-              if (rest) {
-                const int bit = __builtin_ctz(rest);
-                rest &= rest - 1;
-                const int slot = off + j;
-                if (slot < MC) {
-                  float dist, pnt[3];
-                  prim_plane_point(cx, nz, bit, dist, pnt);
-                  S.cdist[slot] = dist;
-                  S.cgeom[slot] = ln;
-                  S.cpos[slot][0] = pnt[0]; S.cpos[slot][1] = pnt[1]; S.cpos[slot][2] = pnt[2];
-                  if (NRM) { S.cnrm[NRM ? slot : 0][0] = 0.f; S.cnrm[NRM ? slot : 0][1] = 0.f; S.cnrm[NRM ? slot : 0][2] = 1.f; }
-                }
+              const int slot = off + j;
+              if (j < cnt && slot < MC) {
+                S.cdist[slot] = stage[j][0];
+                S.cgeom[slot] = ln;
+                S.cpos[slot][0] = stage[j][1]; S.cpos[slot][1] = stage[j][2]; S.cpos[slot][2] = stage[j][3];
+                if (NRM) { S.cnrm[NRM ? slot : 0][0] = 0.f; S.cnrm[NRM ? slot : 0][1] = 0.f; S.cnrm[NRM ? slot : 0][2] = 1.f; }
               }
             }
           }
