@@ -815,7 +815,7 @@ def test_two_envs_per_wave_variant_agrees_with_the_default_kernel(parity):
     a.step(act); b.step(act)
     qa, qb = a.get_data().qvel.clone(), b.get_data().qvel.clone()
     ev = (qa - qb).abs().max(dim=1).values
-    assert float(ev.median()) < 1e-5 and float(ev.quantile(0.95)) < 1e-3, (float(ev.median()), float(ev.max()))
+    assert float(ev.median()) < 5e-5 and float(ev.quantile(0.95)) < 1e-3, (float(ev.median()), float(ev.max()))
     with pytest.raises((ValueError, RuntimeError)):                      # odd env counts keep the default kernel
         BatchedEnv(cfg, num_envs=3, auto_reset=False).engine.set_param("envs_per_wave", np.array([2.0]))
     a.close(); b.close()
