@@ -90,6 +90,26 @@ __device__ __forceinline__ float wave_sum(float v) {
   v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x143, 0xC, 0xF, false));
   return rl(v, 63);
 }
+// Three wave sums at once.  A DPP instruction may read a register only two wait states after the VALU instruction that wrote it, and
+// left to itself the compiler reduces one value at a time through one register (add_dpp / s_nop 1 / add_dpp / ...: 17 issue slots per
+// sum, all dependent).  Interleaved, each step of one sum sits two instructions behind its predecessor: no wait states, 7 slots per
+// sum.  row_bcast adds write only the rows of their mask (the other rows keep their value, which is what the sum needs).
+__device__ __forceinline__ void wave_sum3(float a, float b, float c, float& sa, float& sb, float& sc) {
+#define DPP3(ctl) "v_add_f32_dpp %3, %3, %3 " ctl "\n\tv_add_f32_dpp %4, %4, %4 " ctl "\n\tv_add_f32_dpp %5, %5, %5 " ctl "\n\t"
+  asm volatile(
+      "s_nop 1\n\t"   // the inputs may have been written by the instruction just before
+      DPP3("quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1")
+      DPP3("quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:1")
+      DPP3("row_half_mirror row_mask:0xf bank_mask:0xf bound_ctrl:1")
+      DPP3("row_mirror row_mask:0xf bank_mask:0xf bound_ctrl:1")
+      DPP3("row_bcast:15 row_mask:0xa bank_mask:0xf")
+      DPP3("row_bcast:31 row_mask:0xc bank_mask:0xf")
+      "v_readlane_b32 %0, %3, 63\n\tv_readlane_b32 %1, %4, 63\n\tv_readlane_b32 %2, %5, 63\n\ts_nop 1"
+      : "=&s"(sa), "=&s"(sb), "=&s"(sc), "+v"(a), "+v"(b), "+v"(c));
+#undef DPP3
+}
+template <int LW>
+__device__ __forceinline__ void grp_sum3(float a, float b, float c, float& sa, float& sb, float& sc);
 __device__ __forceinline__ float wave_min(float v) {
   v = fminf(v, dpp<0xB1>(v));
   v = fminf(v, dpp<0x4E>(v));
@@ -110,6 +130,11 @@ __device__ __forceinline__ float grp_sum(float v) {
     v = row_sum(v);
     return v + __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v), 0x401F));   // partner row of the 32-lane group (xor 16)
   }
+}
+template <int LW>
+__device__ __forceinline__ void grp_sum3(float a, float b, float c, float& sa, float& sb, float& sc) {
+  if constexpr (LW == 64) wave_sum3(a, b, c, sa, sb, sc);
+  else { sa = grp_sum<LW>(a); sb = grp_sum<LW>(b); sc = grp_sum<LW>(c); }
 }
 template <int LW>
 __device__ __forceinline__ float grp_min(float v) {
@@ -725,7 +750,9 @@ __global__ __launch_bounds__(64, (EPW == 2 ? 2 : (163840 / (int)sizeof(typename 
           q2m(ximat, qi);
           bmass = S.p_mass[b];
         }
-        const float sx = grp_sum<LW>(bmass * xip[0]), sy = grp_sum<LW>(bmass * xip[1]), sz = grp_sum<LW>(bmass * xip[2]), sm = grp_sum<LW>(bmass);
+        float sx, sy, sz;
+        grp_sum3<LW>(bmass * xip[0], bmass * xip[1], bmass * xip[2], sx, sy, sz);
+        const float sm = grp_sum<LW>(bmass);
         const float inv = 1.f / fmaxf(sm, 1e-20f);
         const float c0 = sx * inv, c1 = sy * inv, c2 = sz * inv;
         if (ln == 0) { S.com[0] = c0; S.com[1] = c1; S.com[2] = c2; }
@@ -796,7 +823,11 @@ __global__ __launch_bounds__(64, (EPW == 2 ? 2 : (163840 / (int)sizeof(typename 
       const unsigned allbodies = ((nbody >= 32 ? 0u : (1u << nbody)) - 1u) & ~1u;
       float crb_all[10];
 #pragma unroll
-      for (int k = 0; k < 10; k++) crb_all[k] = grp_sum<LW>((ln > 0 && ln < nbody) ? cinert[k] : 0.f);
+      for (int k = 0; k < 9; k += 3) {
+        const bool inb = ln > 0 && ln < nbody;
+        grp_sum3<LW>(inb ? cinert[k] : 0.f, inb ? cinert[k + 1] : 0.f, inb ? cinert[k + 2] : 0.f, crb_all[k], crb_all[k + 1], crb_all[k + 2]);
+      }
+      crb_all[9] = grp_sum<LW>((ln > 0 && ln < nbody) ? cinert[9] : 0.f);
       if (ln < NV) {
         const LaneRec& R = dm.rec[ln];
         float crb[10];
@@ -883,7 +914,7 @@ __global__ __launch_bounds__(64, (EPW == 2 ? 2 : (163840 / (int)sizeof(typename 
       WSYNC();
       float cfb_all[6];   // the whole tree's wrench, for the free joint's dofs: group reductions instead of a 13-body loop
 #pragma unroll
-      for (int q = 0; q < 6; q++) cfb_all[q] = grp_sum<LW>(cfb_l[q]);
+      for (int q = 0; q < 6; q += 3) grp_sum3<LW>(cfb_l[q], cfb_l[q + 1], cfb_l[q + 2], cfb_all[q], cfb_all[q + 1], cfb_all[q + 2]);
       if (ln < NV) {
         const LaneRec& R = dm.rec[ln];
         const unsigned sub = dm.rec[R.d_body].b_subtree;
@@ -1697,7 +1728,7 @@ __global__ __launch_bounds__(64, (EPW == 2 ? 2 : (163840 / (int)sizeof(typename 
       Ma = mulM(S.qacc);
       float qacc_l = ln < NV ? S.qacc[ln] : 0.f;
       const float qsm_l = ln < NV ? S.qsm[ln] : 0.f;
-      float cost = 0.f, gauss = 0.f, grad_l = 0.f;
+      float cost = 0.f, gauss = 0.f, grad_l = 0.f, gradnorm2 = 0.f;
       const float scale = 1.f / (meaninertia * (float)(NV > 1 ? NV : 1));
       int niter = 0;
       const int maxiter = min(dm.iterations, A.max_newton);
@@ -1791,9 +1822,13 @@ __global__ __launch_bounds__(64, (EPW == 2 ? 2 : (163840 / (int)sizeof(typename 
           }
           S.qcon[ln] = qc;
         }
-        gauss = grp_sum<LW>(ln < NV ? (0.5f * Ma - qsm_l) * qacc_l : 0.f);
-        cost = grp_sum<LW>(csum) + gauss;
         grad_l = ln < NV ? Ma - qsm_l - qc : 0.f;
+        {   // Gauss term, constraint cost and |grad|^2 in one interleaved reduction
+          float sc_, sg_;
+          grp_sum3<LW>(ln < NV ? (0.5f * Ma - qsm_l) * qacc_l : 0.f, csum, grad_l * grad_l, gauss, sc_, sg_);
+          cost = sc_ + gauss;
+          gradnorm2 = sg_;
+        }
       };
 
       auto update_search = [&](bool act) {
@@ -1953,7 +1988,7 @@ __global__ __launch_bounds__(64, (EPW == 2 ? 2 : (163840 / (int)sizeof(typename 
       };
 
       update_constraint();
-      float gradnorm = sqrtf(grp_sum<LW>(grad_l * grad_l));
+      float gradnorm = sqrtf(gradnorm2);
       if (A.mode == MODE_DEBUG && A.dbg != nullptr) {
         // dump position/velocity-stage intermediates before the solve
         float* D = A.dbg;
@@ -2008,9 +2043,10 @@ __global__ __launch_bounds__(64, (EPW == 2 ? 2 : (163840 / (int)sizeof(typename 
             }
           }
         }
-        const float snorm = sqrtf(grp_sum<LW>(sr_l * sr_l));
+        float sn2_, qG1, qG2;
+        grp_sum3<LW>(sr_l * sr_l, sr_l * (Ma - qsm_l), 0.5f * sr_l * Mv, sn2_, qG1, qG2);
+        const float snorm = sqrtf(sn2_);
         if (!(snorm >= 1e-20f)) return false;
-        const float qG1 = grp_sum<LW>(sr_l * (Ma - qsm_l)), qG2 = grp_sum<LW>(0.5f * sr_l * Mv);
         const float gtol = A.tol32 * A.ls_scale * dm.ls_tolerance * snorm / scale;
         struct Pnt { float alpha, cost, d0, d1, step; };   // step = -d0 / d1 (Newton step of the 1-D search; v_rcp_f32: 1 ulp is ample)
         auto eval = [&](float alpha) -> Pnt {
@@ -2043,7 +2079,9 @@ __global__ __launch_bounds__(64, (EPW == 2 ? 2 : (163840 / (int)sizeof(typename 
               }
             }
           }
-          float C0 = grp_sum<LW>(c0) + gauss, C1 = grp_sum<LW>(c1) + qG1, C2 = grp_sum<LW>(c2) + qG2;
+          float C0, C1, C2;
+          grp_sum3<LW>(c0, c1, c2, C0, C1, C2);
+          C0 += gauss; C1 += qG1; C2 += qG2;
           Pnt p;
           p.alpha = alpha;
           p.cost = alpha * alpha * C2 + alpha * C1 + C0;
@@ -2143,7 +2181,7 @@ __global__ __launch_bounds__(64, (EPW == 2 ? 2 : (163840 / (int)sizeof(typename 
         if (ln < NV) S.qacc[ln] = qacc_l;
         const float oldcost = cost;
         update_constraint();
-        gradnorm = sqrtf(grp_sum<LW>(grad_l * grad_l));
+        gradnorm = sqrtf(gradnorm2);
         niter++;
         if (PROF) { __builtin_amdgcn_s_waitcnt(0); unsigned long long t_ = __builtin_amdgcn_s_memtime(); pacc[14] += t_ - q1_; }   // move + constraint update
         const float improvement = scale * (oldcost - cost);
