@@ -17,8 +17,15 @@
  *
  * PARITY UNPINNED at the MuJoCo boundary: the reference ships no test, golden vector or recorded
  * trajectory for this path and MuJoCo cannot be run in this container.  What
- * pins this file instead: analytic known-answer tests (tests/test_oracle_physics.py) and the
- * golden vectors captured from the reference's importable pure-Python pieces (tests/golden/).
+ * pins this file instead: analytic known-answer tests (tests/test_oracle_physics.py), closed-form
+ * known answers of the published constraint model on hand-built one-body models
+ * (tests/test_oracle_kat.py: impedance interpolation a1 = (1 - d) a0 + d aref, solimp curve, (K, B)
+ * from solref, Huber friction loss, limit row, cone edges and friction mixing) and the golden
+ * vectors captured from the reference's importable pure-Python pieces (tests/golden/).  Still
+ * flagged "restated from memory, nothing independent confirms it": the pyramidal regulariser
+ * (diagApprox = tran (1 + mu^2), Rpy = 2 mu^2 R; its observable consequence is fixed by
+ * test_sphere_rest_penetration_documents_the_pyramidal_regulariser), per-row impedance of connect
+ * constraints, the bracketing details of the line search, plane-mesh neighbour contacts, and MPR.
  */
 #include <math.h>
 #include <stdio.h>
