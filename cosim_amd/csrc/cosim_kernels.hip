@@ -242,7 +242,8 @@ struct CtLds {
   int pgeom[MCP];
   // the four pyramid rows of a ground contact are base +- x1, base +- x2 (n +- mu t1, n +- mu t2): three numbers per contact
   float cD[MC], cJar[MC][3], cJv[MC][3];
-  float tw[NB][6], bw[NB][6], bW[NB][21];
+  float tw[NB][6], bw[NB][6];
+  alignas(16) float bW[NB][24];   // 21 used; rows padded so that the tree pass reads them as six 16-byte words
   unsigned cbmask;   // bodies that carry a ground contact
   // heightfield narrowphase, per geom: end of its (geom, prism) work items in the flattened list, contacts found so far, sub-grid
   // origin, prisms per strip row, lowest point of the geom
@@ -270,7 +271,7 @@ struct EnvLds : CtLds<(MCT > 0), HFL, NB, (MCT > 0 ? MCT : 1), (MCPT > 0 ? MCPT 
   static constexpr int NUMAX = NV - 6;   // actuators: at most one per hinge dof (the free joint's six dofs carry none)
   float qpos[CS_MAXQ], qvel[NV], qacc[NV], qact[NV], qsm[NV], qcon[NV], sr[NV], dofD[NV];
   float xpos[NB][3], xquat[NB][4], xanc[NB][3], xax[NB][3];
-  float cdof[NV][6];
+  alignas(8) float cdof[NV][6];
   float M[NV][LD];
   union {                      // scratch that is dead before the solver starts shares the Hessian's space
     float H[NV][LD];
@@ -1908,10 +1909,12 @@ __global__ __launch_bounds__(64, (EPW == 2 ? 2 : (163840 / (int)sizeof(typename 
             // unit rows (frictionloss, limits) only touch the diagonal: added in LDS (one dynamic access) so that the row
             // comes out as plain reads; lanes past NV factor a copy of row 0, which nobody reads
             if (ln < NV) S.u.H[ln][ln] += S.dofD[ln];
+            unsigned long long th0_ = 0;
             if constexpr (CT) {
               // J^T D J of the active ground-contact rows: per body the 6 x 6 matrix sum_e D w_e w_e^T (lower triangle), then through
               // the tree like a composite inertia: H[i][j] += cdof_i^T (sum over the subtree of i) cdof_j for j an ancestor of i
-              for (int i = ln; i < nbody * 21; i += LW) (&S.bW[0][0])[i] = 0.f;
+              if (PROF) { __builtin_amdgcn_s_waitcnt(0); th0_ = __builtin_amdgcn_s_memtime(); }
+              for (int i = ln; i < nbody * 24; i += LW) (&S.bW[0][0])[i] = 0.f;
               WSYNC();
 #pragma unroll
               for (int cc = 0; cc < CPL; cc++) {
@@ -1940,40 +1943,48 @@ __global__ __launch_bounds__(64, (EPW == 2 ? 2 : (163840 / (int)sizeof(typename 
                 }
               }
               WSYNC();
+              if (PROF && !HF) { __builtin_amdgcn_s_waitcnt(0); const unsigned long long t_ = __builtin_amdgcn_s_memtime(); pext[1] += t_ - th0_; th0_ = t_; }   // flat kernels: [17] = contact-matrix accumulation
+            }
+            const float* Hr = S.u.H[ln < NV ? ln : 0];
+#pragma unroll
+            for (int k = 0; k < NV; k++) a_row[k] = Hr[k];
+            if constexpr (CT) {
+              // tree pass, straight into the row this lane factorises (only the lower triangle of H is read by the factorisation, and row
+              // i's entries j <= i are exactly i's ancestors): y = (sum of the subtree's matrices) cdof_i, then a_row[j] += cdof_j . y
               if (ln < NV) {
                 const LaneRec& R = dm.rec[ln];
                 const unsigned sub = dm.rec[R.d_body].b_subtree & cbmask;
                 if (sub) {
-                  float Wc[21];
-#pragma unroll
-                  for (int i = 0; i < 21; i++) Wc[i] = 0.f;
-                  for (unsigned mk = sub; mk; mk &= mk - 1) {
-                    const int b = __builtin_ctz(mk);
-#pragma unroll
-                    for (int i = 0; i < 21; i++) Wc[i] += S.bW[b][i];
-                  }
                   float cdi[6], y[6];
 #pragma unroll
                   for (int q = 0; q < 6; q++) { cdi[q] = S.cdof[ln][q]; y[q] = 0.f; }
+                  for (unsigned mk = sub; mk; mk &= mk - 1) {
+                    const float4* Wb4 = reinterpret_cast<const float4*>(S.bW[__builtin_ctz(mk)]);
+                    float Wb[24];
 #pragma unroll
-                  for (int i = 0, x = 0; i < 6; i++)
+                    for (int q = 0; q < 6; q++) { const float4 w4 = Wb4[q]; Wb[4 * q] = w4.x; Wb[4 * q + 1] = w4.y; Wb[4 * q + 2] = w4.z; Wb[4 * q + 3] = w4.w; }
 #pragma unroll
-                    for (int j = 0; j <= i; j++, x++) { y[i] += Wc[x] * cdi[j]; if (j != i) y[j] += Wc[x] * cdi[i]; }
-                  for (unsigned mk = R.d_ancmask; mk; mk &= mk - 1) {
-                    const int j = __builtin_ctz(mk);
-                    float v = 0.f;
+                    for (int i = 0; i < 6; i++)
 #pragma unroll
-                    for (int q = 0; q < 6; q++) v += S.cdof[j][q] * y[q];
-                    S.u.H[ln][j] += v;
-                    if (j != ln) S.u.H[j][ln] += v;
+                      for (int j = 0; j <= i; j++) {
+                        const float wv = Wb[i * (i + 1) / 2 + j];
+                        y[i] += wv * cdi[j];
+                        if (j != i) y[j] += wv * cdi[i];
+                      }
+                  }
+                  const unsigned anc = R.d_ancmask;
+#pragma unroll
+                  for (int k = 0; k < NV; k++) {
+                    if ((anc >> k) & 1u) {
+                      const float2* ck = reinterpret_cast<const float2*>(S.cdof[k]);
+                      const float2 c0 = ck[0], c1 = ck[1], c2 = ck[2];
+                      a_row[k] += c0.x * y[0] + c0.y * y[1] + c1.x * y[2] + c1.y * y[3] + c2.x * y[4] + c2.y * y[5];
+                    }
                   }
                 }
               }
+              if (PROF && !HF) { __builtin_amdgcn_s_waitcnt(0); pext[2] += __builtin_amdgcn_s_memtime() - th0_; }   // [18] = tree pass
             }
-            WSYNC();
-            const float* Hr = S.u.H[ln < NV ? ln : 0];
-#pragma unroll
-            for (int k = 0; k < NV; k++) a_row[k] = Hr[k];
           }
           chol_lower<NV, LW>(a_row, dinv, ln, hb);
           WSYNC();

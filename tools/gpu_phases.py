@@ -47,3 +47,4 @@ if acc[19] > 0:
           f"full batches {acc[18]/sub:.0f}")
 elif acc[16] > 0:
     print(f"  robot-robot pairs (broadphase + MPR): {acc[16]:.0f} cycles = {100*acc[16]/tot:.1f} % of the step")
+    print(f"  contact-twist Hessian: per-body matrices {acc[17]:.0f} cycles ({100*acc[17]/tot:.1f} %), tree pass {acc[18]:.0f} cycles ({100*acc[18]/tot:.1f} %)")
