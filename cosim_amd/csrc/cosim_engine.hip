@@ -48,6 +48,7 @@ struct cosim_engine {
   int max_ls = 24;
   int nsub_override = 0;
   int pair_coop = 1;
+  int pair_boxbox = 1;
   int prio[4] = {6, -4, -2, 0};   // wave priority by solver lag (see the kernel): usual iterations per substep, lag thresholds
   // timing
   bool timing = false;
@@ -563,6 +564,7 @@ int cosim_set_param(cosim_engine_t* e, const char* name, const float* host, int 
     }
     return COSIM_OK;
   }
+  else if (n == "boxbox_mode") { e->pair_boxbox = (int)host[0] != 0; return COSIM_OK; }   // 1: box-box pairs through mjc_BoxBox (default), 0: through MPR
   else if (n == "pair_mode") { e->pair_coop = (int)host[0] != 0; return COSIM_OK; }   // 1: hull pairs one at a time, wave-cooperative scans
   else if (n == "envs_per_wave") {   // 2: the two-environments-per-wave kernel (flat flamingo_light_v1, even env counts); 1: one per wave
     const int w = (int)host[0];
@@ -597,7 +599,7 @@ static KArgs base_args(cosim_engine* e) {
   a.hull_vert = e->d_hull_vert; a.hull_adr = e->d_hull_adr; a.hull_nbr = e->d_hull_nbr; a.hfield = e->d_hfield;
   a.pairs = e->d_pairs; a.gext = e->d_gext;
   a.n_envs = e->n_envs; a.seed_lo = (unsigned)e->seed; a.seed_hi = (unsigned)(e->seed >> 32); a.env_id0 = e->env_id0;
-  a.tol32 = e->tol32; a.ls_scale = e->ls_scale; a.max_newton = e->max_newton; a.max_ls = e->max_ls; a.nsub_override = e->nsub_override; a.pair_coop = e->pair_coop;
+  a.tol32 = e->tol32; a.ls_scale = e->ls_scale; a.max_newton = e->max_newton; a.max_ls = e->max_ls; a.nsub_override = e->nsub_override; a.pair_coop = e->pair_coop; a.pair_boxbox = e->pair_boxbox;
   for (int k = 0; k < 4; k++) a.prio[k] = e->prio[k];
   return a;
 }

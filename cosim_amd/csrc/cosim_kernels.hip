@@ -64,6 +64,7 @@ struct KArgs {
   int max_newton, max_ls;
   int nsub_override;      // > 0: physics substeps per control step (diagnostics; 0 = the model's frame_skip)
   int pair_coop;          // robot-robot pairs with a hull: 1 = one at a time, wave-cooperative vertex scans; 0 = lane-parallel
+  int pair_boxbox;        // box-box pairs: 1 = mjc_BoxBox (up to eight contacts), 0 = through MPR like the other convex pairs (one contact)
   int prio[4];            // wave priority by solver lag: expected Newton iterations per substep, then the three lag thresholds
 };
 
@@ -512,6 +513,7 @@ __device__ __forceinline__ float terrain_height(const Terrain& T, float x, float
 
 }  // namespace cosim
 #include "cosim_mpr.h"
+#include "cosim_boxbox.h"
 namespace cosim {
 // ------------------------------------------------------------------------------------------------ impedance (mj_makeImpedance)
 __device__ __forceinline__ float impedance(const float* solimp, float pos, float margin) {
@@ -1389,7 +1391,7 @@ __global__ __launch_bounds__(64, (EPW == 2 ? 2 : (163840 / (int)sizeof(typename 
         const int npair = dm.npair;
         for (int p0 = 0; p0 < npair; p0 += 64) {
           const int p = p0 + ln;
-          bool cand = false, mesh = false;
+          bool cand = false, mesh = false, boxes = false;
           int g1 = 0, g2 = 0;
           if (p < npair) {
             const unsigned pk = A.pairs[p];
@@ -1445,10 +1447,11 @@ __global__ __launch_bounds__(64, (EPW == 2 ? 2 : (163840 / (int)sizeof(typename 
             // pairs with a convex hull: one at a time with all 64 lanes sharing the vertex scans (cosim_set_param "pair_mode" 0 runs them
             // lane-parallel, every lane scanning its own hulls: measured slower on the 700-vertex wheel hulls)
             mesh = cand && A.pair_coop && (G1.g_type == CS_GEOM_MESH || G2.g_type == CS_GEOM_MESH);
+            if constexpr ((GTM & GT_BOX) != 0) boxes = cand && A.pair_boxbox && G1.g_type == CS_GEOM_BOX && G2.g_type == CS_GEOM_BOX;
           }
           bool hit = false;
           float depth = 0.f, cn[3] = {0.f, 0.f, 1.f}, cp[3] = {0.f, 0.f, 0.f};
-          if (cand && !mesh) {
+          if (cand && !mesh && !boxes) {
             CObj o1, o2;
             make_cobj(o1, g1);
             make_cobj(o2, g2);
@@ -1460,6 +1463,24 @@ __global__ __launch_bounds__(64, (EPW == 2 ? 2 : (163840 / (int)sizeof(typename 
             const int slot = (CT ? npc : ncon) + __popcll(hm & lanemask_lt(ln));
             if (hit) pair_put(slot, -depth, g2 | ((g1 + 1) << 8), cp, cn);
             if constexpr (CT) npc += __popcll(hm); else ncon += __popcll(hm);
+          }
+          if constexpr ((GTM & GT_BOX) != 0) {
+            // box-box (mjc_BoxBox): one pair at a time, the lanes share the clipping of the incident face (cosim_boxbox.h)
+            unsigned long long bm = __ballot(boxes);
+            while (bm) {
+              const int src = __builtin_ctzll(bm);
+              bm &= bm - 1;
+              const int h1 = __shfl(g1, src, 64), h2 = __shfl(g2, src, 64);
+              CObj o1, o2;
+              make_cobj(o1, h1);
+              make_cobj(o2, h2);
+              float bp[3], bn[3] = {0.f, 0.f, 1.f}, bd = 0.f;
+              const bool okb = box_box_lane(o1.pos, o1.q, o1.size, o2.pos, o2.q, o2.size, fmaxf(dm.rec[h1].g_margin, dm.rec[h2].g_margin), ln, bp, bd, bn);
+              const unsigned long long km = __ballot(okb);
+              const int rank = __popcll(km & lanemask_lt(ln)), cnt = min((int)__popcll(km), 8);
+              if (okb && rank < 8) pair_put((CT ? npc : ncon) + rank, bd, h2 | ((h1 + 1) << 8), bp, bn);
+              if constexpr (CT) npc += cnt; else ncon += cnt;
+            }
           }
           if constexpr ((GTM & GT_MESH) != 0) {
             unsigned long long mm = __ballot(mesh);

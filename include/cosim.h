@@ -83,7 +83,8 @@ int cosim_query(const cosim_engine_t* e, const char* name);
  * "max_ls" (iteration caps below the model's), "envs_per_wave" (1 | 2: kernel variant, 2 only for flat flamingo_light_v1 and
  * even env counts), "wave_priority" (count 4: s_setprio by solver lag -- Newton iterations taken as usual per substep, then the
  * lag thresholds of priority 1, 2, 3; a huge first threshold switches it off), "debug_substeps" (diagnostics: physics substeps
- * per control step, 0 = frame_skip). */
+ * per control step, 0 = frame_skip), "boxbox_mode" (1, default: box-box geom pairs through the mjc_BoxBox routine, up to eight contacts
+ * per pair; 0: through MPR like the other convex pairs, one contact). */
 int cosim_set_param(cosim_engine_t* e, const char* name, const float* host, int count);
 
 /* Replaces env.reset() (reference envs/wrappers.py:245-256,303-307,385-389; flamingo_light_v1.py:209-232).

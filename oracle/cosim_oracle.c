@@ -13,7 +13,8 @@
  * tag 3.2.7; the upstream function each block follows is named in its comment) for exactly the
  * feature set the four cosim MJCF files use: free + hinge joints, implicitfast integrator, Newton
  * solver with exact line search, pyramidal cones, connect equalities, dof frictionloss, joint limits,
- * plane/hfield ground against sphere / cylinder / box / convex-mesh geoms, motors, IMU sensors.
+ * plane/hfield ground against sphere / cylinder / box / convex-mesh geoms, robot-robot pairs (MPR;
+ * box-box manifolds), motors, IMU sensors.
  *
  * PARITY UNPINNED at the MuJoCo boundary: the reference ships no test, golden vector or recorded
  * trajectory for this path and MuJoCo cannot be run in this container.  What
@@ -25,7 +26,9 @@
  * flagged "restated from memory, nothing independent confirms it": the pyramidal regulariser
  * (diagApprox = tran (1 + mu^2), Rpy = 2 mu^2 R; its observable consequence is fixed by
  * test_sphere_rest_penetration_documents_the_pyramidal_regulariser), per-row impedance of connect
- * constraints, the bracketing details of the line search, plane-mesh neighbour contacts, and MPR.
+ * constraints, the bracketing details of the line search, plane-mesh neighbour contacts, MPR, and
+ * the box-box routine (structure of mjc_BoxBox; its clipped manifolds are pinned by closed-form
+ * geometry only, test_box_box_manifolds_have_closed_form_vertices).
  */
 #include <math.h>
 #include <stdio.h>
@@ -83,6 +86,7 @@ typedef struct oracle_data {
   double solver_cost;
   int contact_overflow;
   int no_self_collision; /* test switch */
+  int boxbox_mpr;        /* test switch: box-box pairs through MPR */
 } oracle_data;
 
 /* ------------------------------------------------------------------ small math (engine_util_*.c) */
@@ -731,6 +735,147 @@ static void convex_convex(oracle_data* d, int g1, int g2) {
   if (c) { c->geom1 = g1; c->body1 = b1; }
 }
 
+/* ------------------------------------------------------------------ box-box (engine_collision_box.c mjc_BoxBox)
+ * MuJoCo's collision table sends box-box pairs to mjc_BoxBox, not to MPR: a separating-axis search over the 15 axes (6 face
+ * normals, 9 edge x edge directions; an edge axis wins only when it beats the best face by more than a 1e-12 relative bias), then
+ *   - face case: the face of the other box most opposed to the winning face (the incident face) is clipped against the winning
+ *     face's rectangle; every vertex of the clipped polygon (at most 8) within `margin` of the reference face is a contact,
+ *     position midway between the incident-face point and the reference face, normal = the face normal (geom1 -> geom2);
+ *   - edge case: one contact midway between the closest points of the two edges.
+ * RESTATED FROM MEMORY OF THE ALGORITHM'S STRUCTURE (PARITY UNPINNED, like MPR above): the enumeration order of the clipped
+ * polygon's vertices -- incident vertices inside the rectangle, rectangle corners inside the incident quad, edge x side
+ * crossings -- is this file's (contact order does not change the Newton solution), and MuJoCo's edge case can emit more than one
+ * point for parallel edges; here parallel edges never win (their cross product is skipped) and fall to the face case.
+ * Humanoid only: humanoid_p_v0.xml:33,40,110,139 (torso / pelvis / forearm boxes), five pairs after the compiled filters. */
+typedef struct { double pos[3], dist; } bb_point_t;
+static void mat_col(double* c, const double* mat, int k) { c[0] = mat[k]; c[1] = mat[3 + k]; c[2] = mat[6 + k]; }
+static int box_box_points(const double* p1, const double* m1, const double* s1, const double* p2, const double* m2, const double* s2,
+                          double margin, bb_point_t* out, double* nrm) {
+  double d[3] = {p2[0] - p1[0], p2[1] - p1[1], p2[2] - p1[2]}, A[3][3], B[3][3];
+  for (int k = 0; k < 3; k++) { mat_col(A[k], m1, k); mat_col(B[k], m2, k); }
+  double best = -1e300, bax[3] = {0, 0, 1};
+  int code = -1;
+  for (int i = 0; i < 3; i++) { /* faces of box 1, then of box 2: separation s = |d.a| - r1 - r2 (negative: penetration) */
+    double r = s1[i];
+    for (int k = 0; k < 3; k++) r += s2[k] * fabs(dot3(B[k], A[i]));
+    double s = fabs(dot3(d, A[i])) - r;
+    if (s > margin) return 0;
+    if (s > best) { best = s; code = i; }
+  }
+  for (int j = 0; j < 3; j++) {
+    double r = s2[j];
+    for (int k = 0; k < 3; k++) r += s1[k] * fabs(dot3(A[k], B[j]));
+    double s = fabs(dot3(d, B[j])) - r;
+    if (s > margin) return 0;
+    if (s > best) { best = s; code = 3 + j; }
+  }
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) {
+      double ax[3];
+      cross3(ax, A[i], B[j]);
+      double l = sqrt(dot3(ax, ax));
+      if (l < 1e-6) continue; /* parallel edges: the face axes decide */
+      for (int k = 0; k < 3; k++) ax[k] /= l;
+      double r = 0;
+      for (int k = 0; k < 3; k++) r += s1[k] * fabs(dot3(A[k], ax)) + s2[k] * fabs(dot3(B[k], ax));
+      double s = fabs(dot3(d, ax)) - r;
+      if (s > margin) return 0;
+      /* penetration_edge < penetration_face (1 - 1e-12), in separations (both negative when penetrating) */
+      if (s > best + 1e-12 * fabs(best)) { best = s; code = 6 + 3 * i + j; memcpy(bax, ax, 24); }
+    }
+  if (code < 0) return 0;
+  if (code >= 6) {
+    int i = (code - 6) / 3, j = (code - 6) % 3;
+    double sg = dot3(bax, d) < 0 ? -1.0 : 1.0, pa[3], pb[3];
+    for (int k = 0; k < 3; k++) { nrm[k] = sg * bax[k]; pa[k] = p1[k]; pb[k] = p2[k]; }
+    for (int k = 0; k < 3; k++) {
+      if (k != i) { double t = dot3(nrm, A[k]) < 0 ? -s1[k] : s1[k]; for (int c = 0; c < 3; c++) pa[c] += t * A[k][c]; }
+      if (k != j) { double t = dot3(nrm, B[k]) < 0 ? -s2[k] : s2[k]; for (int c = 0; c < 3; c++) pb[c] -= t * B[k][c]; }
+    }
+    double pp[3] = {pb[0] - pa[0], pb[1] - pa[1], pb[2] - pa[2]};
+    double uaub = dot3(A[i], B[j]), q1 = dot3(A[i], pp), q2 = -dot3(B[j], pp), den = 1 - uaub * uaub;
+    double al = (q1 + uaub * q2) / den, be = (uaub * q1 + q2) / den;
+    for (int k = 0; k < 3; k++) out[0].pos[k] = 0.5 * (pa[k] + al * A[i][k] + pb[k] + be * B[j][k]);
+    out[0].dist = best;
+    return 1;
+  }
+  /* face case: reference box R (the face's owner), incident box O */
+  int ref2 = code >= 3, a = code % 3, a1 = (a + 1) % 3, a2 = (a + 2) % 3;
+  const double *pr = ref2 ? p2 : p1, *po = ref2 ? p1 : p2, *sr = ref2 ? s2 : s1, *so = ref2 ? s1 : s2;
+  double(*Rr)[3] = ref2 ? B : A, (*Ro)[3] = ref2 ? A : B;
+  double dro[3] = {po[0] - pr[0], po[1] - pr[1], po[2] - pr[2]}, nr[3];
+  double sg = dot3(dro, Rr[a]) < 0 ? -1.0 : 1.0;
+  for (int k = 0; k < 3; k++) { nr[k] = sg * Rr[a][k]; nrm[k] = ref2 ? -nr[k] : nr[k]; }
+  int b = 0;
+  double bm = -1;
+  for (int k = 0; k < 3; k++) { double v = fabs(dot3(Ro[k], nr)); if (v > bm) { bm = v; b = k; } }
+  int k1 = (b + 1) % 3, k2 = (b + 2) % 3;
+  double mo[3], fc[3], sb = dot3(Ro[b], nr) < 0 ? 1.0 : -1.0; /* the face of O that looks back at R */
+  for (int k = 0; k < 3; k++) { mo[k] = sb * Ro[b][k]; fc[k] = po[k] + sb * so[b] * Ro[b][k] - pr[k]; } /* relative to R's centre */
+  static const double SQ[4][2] = {{-1, -1}, {1, -1}, {1, 1}, {-1, 1}};
+  double v[4][3], vu[4], vw[4];
+  for (int q = 0; q < 4; q++) {
+    for (int k = 0; k < 3; k++) v[q][k] = fc[k] + SQ[q][0] * so[k1] * Ro[k1][k] + SQ[q][1] * so[k2] * Ro[k2][k];
+    vu[q] = dot3(v[q], Rr[a1]); vw[q] = dot3(v[q], Rr[a2]);
+  }
+  double h1 = sr[a1], h2 = sr[a2], mn = dot3(mo, nr);
+  int n = 0;
+#define BB_EMIT(X)                                                                                                     \
+  do {                                                                                                                 \
+    double depth_ = sr[a] - dot3((X), nr);                                                                             \
+    if (-depth_ <= margin && n < 8) {                                                                                  \
+      for (int k_ = 0; k_ < 3; k_++) out[n].pos[k_] = pr[k_] + (X)[k_] + 0.5 * depth_ * nr[k_];                        \
+      out[n++].dist = -depth_;                                                                                         \
+    }                                                                                                                  \
+  } while (0)
+  for (int q = 0; q < 4; q++) /* (A) incident vertices inside the rectangle */
+    if (fabs(vu[q]) <= h1 && fabs(vw[q]) <= h2) BB_EMIT(v[q]);
+  for (int q = 0; q < 4; q++) { /* (B) rectangle corners strictly inside the projected incident quad, lifted onto the incident face */
+    double cu = SQ[q][0] * h1, cw = SQ[q][1] * h2;
+    int pos_ = 0, neg_ = 0;
+    for (int e = 0; e < 4; e++) {
+      int f = (e + 1) & 3;
+      double cr = (vu[f] - vu[e]) * (cw - vw[e]) - (vw[f] - vw[e]) * (cu - vu[e]);
+      if (cr > 0) pos_++; else if (cr < 0) neg_++; else { pos_ = neg_ = 1; }
+    }
+    if (pos_ && neg_) continue;
+    double x[3], num = 0;
+    for (int k = 0; k < 3; k++) { x[k] = cu * Rr[a1][k] + cw * Rr[a2][k]; num += mo[k] * (fc[k] - x[k]); }
+    double z = num / mn;
+    for (int k = 0; k < 3; k++) x[k] += z * nr[k];
+    BB_EMIT(x);
+  }
+  for (int q = 0; q < 4; q++) { /* (C) incident edge q -> q+1 against the four sides u = +h1, u = -h1, w = +h2, w = -h2 */
+    int f = (q + 1) & 3;
+    for (int e = 0; e < 4; e++) {
+      double c0 = e < 2 ? vu[q] : vw[q], c1 = e < 2 ? vu[f] : vw[f], lim = (e & 1 ? -1.0 : 1.0) * (e < 2 ? h1 : h2);
+      double o0 = e < 2 ? vw[q] : vu[q], o1 = e < 2 ? vw[f] : vu[f], ho = e < 2 ? h2 : h1;
+      if ((c0 - lim) * (c1 - lim) >= 0) continue; /* strictly across the side's line */
+      double t = (lim - c0) / (c1 - c0), oo = o0 + t * (o1 - o0);
+      if (fabs(oo) >= ho) continue;                /* corners of the rectangle belong to (B) */
+      double x[3];
+      for (int k = 0; k < 3; k++) x[k] = v[q][k] + t * (v[f][k] - v[q][k]);
+      BB_EMIT(x);
+    }
+  }
+#undef BB_EMIT
+  return n;
+}
+
+static void box_box(oracle_data* d, int g1, int g2) {
+  const cosim_model_t* m = &d->m;
+  double p1[3], m1[9], p2[3], m2[9], nrm[3];
+  geom_pose(d, g1, p1, m1);
+  geom_pose(d, g2, p2, m2);
+  double margin = fmax(m->geom_margin[g1], m->geom_margin[g2]);
+  bb_point_t pt[8];
+  int n = box_box_points(p1, m1, m->geom_size[g1], p2, m2, m->geom_size[g2], margin, pt, nrm);
+  for (int i = 0; i < n; i++) {
+    contact_t* c = add_contact(d, g2, pt[i].dist, pt[i].pos, nrm);
+    if (c) { c->geom1 = g1; c->body1 = m->geom_bodyid[g1]; }
+  }
+}
+
 /* mj_contactParam (engine_collision_driver.c): equal priority -> solmix weighting, friction = elementwise max */
 static void contact_param(const oracle_data* d, contact_t* c) {
   const cosim_model_t* m = &d->m;
@@ -787,7 +932,9 @@ static void collision(oracle_data* d) {
   /* robot-robot pairs that pass the contype/conaffinity, same-body, parent-child and <exclude> filters (compiled list) */
   for (int p = 0; p < m->npair && !d->no_self_collision; p++) {
     int first = d->ncon;
-    convex_convex(d, m->pair_geom1[p], m->pair_geom2[p]);
+    int g1 = m->pair_geom1[p], g2 = m->pair_geom2[p];
+    if (m->geom_type[g1] == CS_GEOM_BOX && m->geom_type[g2] == CS_GEOM_BOX && !d->boxbox_mpr) box_box(d, g1, g2);
+    else convex_convex(d, g1, g2);
     for (int i = first; i < d->ncon; i++) contact_param(d, &d->con[i]);
   }
 }
@@ -1579,6 +1726,14 @@ int oracle_mpr_pair(oracle_data* d, int g1, int g2, double* out7) {
   return mpr_penetration(&o1, &o2, out7, out7 + 1, out7 + 4);
 }
 void oracle_set_self_collision(oracle_data* d, int on) { d->no_self_collision = !on; }
+void oracle_set_boxbox_mpr(oracle_data* d, int on) { d->boxbox_mpr = on; } /* 1: box-box pairs through MPR (one contact), as before mjc_BoxBox was restated */
+/* box-box between two boxes given directly (pose = pos3 + row-major mat9); out = up to 8 x {pos3, dist}, nrm3 = normal box1 -> box2 */
+int oracle_box_box(const double* pose1, const double* size1, const double* pose2, const double* size2, double margin, double* out32, double* nrm3) {
+  bb_point_t pt[8];
+  int n = box_box_points(pose1, pose1 + 3, size1, pose2, pose2 + 3, size2, margin, pt, nrm3);
+  for (int i = 0; i < n; i++) { memcpy(out32 + 4 * i, pt[i].pos, 24); out32[4 * i + 3] = pt[i].dist; }
+  return n;
+}
 void oracle_mpr_stats(long* out3) { out3[0] = g_mpr_calls; out3[1] = g_mpr_supports; out3[2] = g_mpr_hits; }
 /* MPR between two primitives given directly (kind: CO_SPHERE/CO_CYLINDER/CO_BOX; pose = pos3 + row-major mat9; size3) */
 int oracle_mpr_prims(int k1, const double* pose1, const double* size1, int k2, const double* pose2, const double* size2, double* out7) {

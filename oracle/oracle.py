@@ -53,6 +53,9 @@ def lib():
         L.oracle_mpr_prims.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
                                        ctypes.c_void_p]
         L.oracle_set_self_collision.argtypes = [ctypes.c_void_p, ctypes.c_int]
+        L.oracle_set_boxbox_mpr.argtypes = [ctypes.c_void_p, ctypes.c_int]
+        L.oracle_box_box.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_double, ctypes.c_void_p,
+                                     ctypes.c_void_p]
         L.oracle_ray_down.restype = ctypes.c_double
         L.oracle_ray_down.argtypes = [ctypes.c_void_p, ctypes.c_double, ctypes.c_double, ctypes.c_double]
         _lib = L
@@ -146,6 +149,10 @@ class Oracle:
     def set_self_collision(self, on: bool):
         self.L.oracle_set_self_collision(self.h, int(on))
 
+    def set_boxbox_mpr(self, on: bool):
+        """True: box-box pairs through MPR (one contact per pair) instead of the mjc_BoxBox restatement."""
+        self.L.oracle_set_boxbox_mpr(self.h, int(on))
+
     def mpr_pair(self, g1: int, g2: int):
         """One MPR query between robot geoms g1, g2 at the current pose: (hit, depth, dir[3] g1->g2, pos[3])."""
         out = np.zeros(7)
@@ -178,3 +185,15 @@ class Oracle:
 
     def ray_down(self, x: float, y: float, z0: float) -> float:
         return self.L.oracle_ray_down(self.h, x, y, z0)
+
+
+def box_box(pos1, mat1, size1, pos2, mat2, size2, margin=0.0):
+    """mjc_BoxBox restatement on two free boxes: (points [n, 3], dist [n], normal[3] box1 -> box2)."""
+    L = lib()
+    p1 = np.concatenate([np.asarray(pos1, float), np.asarray(mat1, float).reshape(9)])
+    p2 = np.concatenate([np.asarray(pos2, float), np.asarray(mat2, float).reshape(9)])
+    s1, s2 = np.ascontiguousarray(size1, dtype=np.float64), np.ascontiguousarray(size2, dtype=np.float64)
+    out, nrm = np.zeros(32), np.zeros(3)
+    n = L.oracle_box_box(p1.ctypes.data, s1.ctypes.data, p2.ctypes.data, s2.ctypes.data, float(margin), out.ctypes.data, nrm.ctypes.data)
+    out = out.reshape(8, 4)[:n]
+    return out[:, :3].copy(), out[:, 3].copy(), nrm

@@ -556,7 +556,7 @@ def test_self_collision_mpr_matches_oracle(env_id, steps, amp):
         gpu = {}
         for gg, gd, gp, gn in _dbg_contacts(dbg):
             if (gg >> 8) - 1 >= 0:
-                gpu[((gg >> 8) - 1, gg & 255)] = (gd, gp, gn)
+                gpu.setdefault(((gg >> 8) - 1, gg & 255), []).append((gd, gp, gn))
         base = R["qpos"][w][:3].copy(); base[2] = 0.0              # the engine works in a base-relative frame
         for c in oc[oc[:, 9] >= 0]:
             key = (int(c[9]), int(c[7]))
@@ -564,7 +564,7 @@ def test_self_collision_mpr_matches_oracle(env_id, steps, amp):
                 miss += c[0] < -1e-5                               # grazing contacts may flip
                 continue
             nmatch += 1
-            gd, gp, gn = gpu[key]
+            gd, gp, gn = min(gpu[key], key=lambda r: np.abs(r[1] + base - c[1:4]).max())   # box-box pairs carry several contacts
             good += abs(gd - c[0]) < 1e-5 and np.abs(gn - c[4:7]).max() < 1e-3 and np.abs(gp + base - c[1:4]).max() < 1e-4
     assert miss == 0 and nmatch >= 20
     # ill-conditioned edge contacts: the final portal can differ between fp32 and fp64 poses; they must stay rare
@@ -577,6 +577,85 @@ def test_self_collision_mpr_matches_oracle(env_id, steps, amp):
     assert np.median(ev[sc]) < 2e-4 and np.quantile(ev[sc], 0.9) < 5e-3, (np.median(ev[sc]), np.quantile(ev[sc], 0.9))
     st = env.solver_stats()
     assert st["dropped_contacts"] == 0 and st["dropped_limit_rows"] == 0 and st["max_contacts"] >= 4   # every state, no capacity mask
+    env.close()
+
+
+@pytest.mark.gpu
+def test_box_box_pairs_match_oracle():
+    """mjc_BoxBox (humanoid_p_v0.xml:33,40,110,139: the only box geoms that can meet): the wave-parallel clipping of
+    cosim_boxbox.h against the oracle's box_box_points on random poses that bring the torso / pelvis / forearm boxes together --
+    same contact count per pair, every contact matched in position, depth and normal -- then one control step through those states
+    (up to eight dense contact rows groups per pair)."""
+    import torch
+    from cosim_amd.batched_env import BatchedEnv
+    from cosim_amd.compile import compile_model
+    from cosim_amd.config import PARITY_RANDOM, make_config
+    from cosim_amd.model import get_field
+    from oracle.oracle import Oracle
+    cfg = make_config("humanoid_p_v0", random=PARITY_RANDOM)
+    cm = compile_model(cfg)
+    b = cm.blob
+    gt = np.array(b.geom_type[:b.ngeom])
+    bb = {(int(b.pair_geom1[p]), int(b.pair_geom2[p])) for p in range(b.npair)}
+    bb = {k for k in bb if gt[k[0]] == 6 and gt[k[1]] == 6}
+    assert len(bb) == 5
+    o = Oracle(cm)
+    q0 = np.array(get_field(b, "init_qpos")[:b.nq])
+    rng = np.random.default_rng(1)
+    adr = np.array([b.jnt_qposadr[j] for j in range(1, b.njnt)])
+    arm = np.array([b.jnt_bodyid[j] for j in range(1, b.njnt)]) >= 13
+    states, ref = [], []
+    for _ in range(8000):                                          # arms anywhere (past their limits too), the rest near the initial pose
+        q = q0.copy()
+        u = rng.uniform(-1, 1, len(adr))
+        q[adr] += np.where(arm, 1.5 * u, 0.05 * u)
+        o.reset(q)
+        o.forward()
+        c = o.contacts()
+        if len(c) and c[:, 0].min() > -0.06 and any((int(r[9]), int(r[7])) in bb for r in c):
+            states.append(q)
+            ref.append(c[[(int(r[9]), int(r[7])) in bb for r in c]])
+    n = len(states)
+    assert n >= 100 and max(len(r) for r in ref) >= 4              # multi-contact manifolds do occur
+    env = BatchedEnv(cfg, num_envs=n, auto_reset=False, compiled=cm)
+    env.reset()
+    env.set_state(np.array(states), np.zeros((n, b.nv)), np.zeros((n, b.nv)))
+    same, good, tot = 0, 0, 0
+    for w in range(n):
+        dbg = env.engine.debug_forward(int(w))
+        gpu = [(((gg >> 8) - 1, gg & 255), gd, gp, gn) for gg, gd, gp, gn in _dbg_contacts(dbg) if ((gg >> 8) - 1, gg & 255) in bb]
+        base = states[w][:3].copy(); base[2] = 0.0
+        same += len(gpu) == len(ref[w])
+        for c in ref[w]:
+            tot += 1
+            cand = [g for g in gpu if g[0] == (int(c[9]), int(c[7]))]
+            if cand:
+                _, gd, gp, gn = min(cand, key=lambda r: np.abs(r[2] + base - c[1:4]).max())
+                good += abs(gd - c[0]) < 2e-5 and np.abs(gn - c[4:7]).max() < 1e-3 and np.abs(gp + base - c[1:4]).max() < 1e-4
+    # face / edge ties and clipped vertices within rounding of the margin may flip between fp32 and fp64
+    assert same >= 0.95 * n and good >= 0.97 * tot, (same, n, good, tot)
+    # the routine against the MPR route it replaces: same states, one contact per pair
+    env.engine.set_param("boxbox_mode", np.array([0.0], dtype=np.float32))
+    for w in range(0, n, 10):
+        keys = [((gg >> 8) - 1, gg & 255) for gg, *_ in _dbg_contacts(env.engine.debug_forward(int(w)))]
+        keys = [k for k in keys if k in bb]
+        assert len(keys) == len(set(keys))
+    env.engine.set_param("boxbox_mode", np.array([1.0], dtype=np.float32))
+    # one control step from those poses (zero velocity): same velocities as the oracle
+    qv1 = []
+    for q in states:
+        o.reset(q)
+        o.control_step(np.zeros(b.nu))
+        qv1.append(o.qvel.copy())
+    env.set_state(np.array(states), np.zeros((n, b.nv)), np.zeros((n, b.nv)))
+    env.step(torch.zeros((n, b.nu), dtype=torch.float32, device=env.device))
+    qv1 = np.array(qv1)
+    # arms released from beyond their limits: |qvel| reaches tens of rad/s within the step, so the error is taken relative to it (the
+    # MPR route on the same states: 3x larger, a single contact on a flat face is ill-conditioned)
+    ev = np.abs(env.get_data().qvel.cpu().numpy().astype(np.float64) - qv1).max(axis=1) / (1.0 + np.abs(qv1).max(axis=1))
+    assert np.median(ev) < 5e-4 and np.quantile(ev, 0.9) < 3e-2, (np.median(ev), np.quantile(ev, 0.9))
+    assert env.solver_stats()["dropped_limit_rows"] == 0
+    assert env.solver_stats()["dropped_contacts"] == 0
     env.close()
 
 

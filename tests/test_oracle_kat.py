@@ -170,3 +170,43 @@ def test_sphere_rest_penetration_documents_the_pyramidal_regulariser(mu, imprati
     assert pens[0] == pytest.approx(p, rel=1e-6) and pens[1] == pytest.approx(p, rel=1e-6)
     for alt in (0.5, 2.0, 1.0 / (1 + mu * mu)):                       # what the alternatives would predict (to first order in d)
         assert abs(pens[0] / (p * alt) - 1) > 0.2 or alt == 1.0
+
+
+def test_box_box_manifolds_have_closed_form_vertices():
+    """mjc_BoxBox restatement (oracle box_box_points; MuJoCo's collision table sends box-box pairs there, not to MPR).  The clipped
+    incident face is elementary geometry: a small box resting on a large one gives its four bottom corners, two equal boxes turned by
+    45 degrees the octagon |x| = h or |y| = h with |x| + |y| = sqrt(2) h, crossed edges one point midway between the edges; contact
+    positions lie midway between the two surfaces and dist = -penetration; `margin` admits separated faces."""
+    from oracle.oracle import box_box
+    I = np.eye(3)
+    pts, dist, n = box_box([0, 0, 0], I, [0.5, 0.5, 0.1], [0.1, 0.05, 0.199], I, [0.1, 0.1, 0.1])
+    assert len(pts) == 4 and np.allclose(dist, -0.001) and np.allclose(n, [0, 0, 1])
+    assert {(round(p[0], 9), round(p[1], 9)) for p in pts} == {(0.0, -0.05), (0.2, -0.05), (0.2, 0.15), (0.0, 0.15)}
+    assert np.allclose(pts[:, 2], 0.0995)
+    # the large box as geom 2: same points, normal still from box 1 to box 2
+    pts2, dist2, n2 = box_box([0.1, 0.05, 0.199], I, [0.1, 0.1, 0.1], [0, 0, 0], I, [0.5, 0.5, 0.1])
+    assert len(pts2) == 4 and np.allclose(dist2, -0.001) and np.allclose(n2, [0, 0, -1]) and np.allclose(pts2[:, 2], 0.0995)
+    c = np.cos(np.pi / 4)
+    Rz = np.array([[c, -c, 0], [c, c, 0], [0, 0, 1]])
+    h = 0.1
+    pts, dist, n = box_box([0, 0, 0], I, [h, h, h], [0, 0, 2 * h - 0.002], Rz, [h, h, h])
+    assert len(pts) == 8 and np.allclose(dist, -0.002) and np.allclose(pts[:, 2], h - 0.001)
+    a = np.abs(pts[:, :2])
+    assert np.allclose(a.max(axis=1), h) and np.allclose(a.sum(axis=1), np.sqrt(2) * h)
+    assert len({(round(p[0], 6), round(p[1], 6)) for p in pts}) == 8
+    Rx = np.array([[1, 0, 0], [0, c, -c], [0, c, c]])
+    Ry = np.array([[c, 0, c], [0, 1, 0], [-c, 0, c]])
+    e = h * np.sqrt(2)
+    pts, dist, n = box_box([0, 0, 0], Ry, [h, h, h], [0, 0, 2 * e - 0.002], Rx, [h, h, h])
+    assert len(pts) == 1 and dist[0] == pytest.approx(-0.002) and np.allclose(np.abs(n), [0, 0, 1]) and n[2] > 0
+    assert np.allclose(pts[0], [0, 0, e - 0.001], atol=1e-12)
+    pts, dist, _ = box_box([0, 0, 0], I, [0.5, 0.5, 0.1], [0.1, 0.05, 0.201], I, [0.1, 0.1, 0.1], margin=0.002)
+    assert len(pts) == 4 and np.allclose(dist, 0.001)
+    assert len(box_box([0, 0, 0], I, [0.5, 0.5, 0.1], [0.1, 0.05, 0.201], I, [0.1, 0.1, 0.1])[0]) == 0
+    # tilted box: only the vertices that dip below the face (or within the margin) are contacts, and the depth is linear along the face
+    t = 0.02
+    Rt = np.array([[np.cos(t), 0, np.sin(t)], [0, 1, 0], [-np.sin(t), 0, np.cos(t)]])
+    pts, dist, n = box_box([0, 0, 0], I, [0.5, 0.5, 0.1], [0, 0, 0.2], Rt, [0.1, 0.1, 0.1])
+    assert len(pts) == 2 and np.allclose(n, [0, 0, 1])
+    zc = 0.2 - 0.1 * np.cos(t) - 0.1 * np.sin(t) - 0.1                          # lowest corners: x = +h side dips
+    assert np.allclose(dist, zc) and np.allclose(pts[:, 0], 0.1 * np.cos(t) - 0.1 * np.sin(t))
