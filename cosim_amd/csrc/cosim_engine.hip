@@ -737,9 +737,9 @@ int cosim_profile_step(cosim_engine_t* e, const float* actions_dev, const float*
   (e->epw == 2 ? e->launch_prof2 : e->launch_prof)(e, a, e->n_envs, 0);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipDeviceSynchronize());
-  unsigned long long raw[24];
+  unsigned long long raw[32];
   HIP_TRY(hipMemcpy(raw, e->d_dbg, sizeof raw, hipMemcpyDeviceToHost));
-  for (int i = 0; i < 24; i++) cycles_out16[i] = (double)raw[i] / (double)(e->n_envs / e->epw);   // per wave
+  for (int i = 0; i < 32; i++) cycles_out16[i] = (double)raw[i] / (double)(e->n_envs / e->epw);   // per wave
   return COSIM_OK;
 }
 

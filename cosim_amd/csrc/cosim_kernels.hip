@@ -585,8 +585,8 @@ __global__ __launch_bounds__(64, (EPW == 2 ? 2 : (163840 / (int)sizeof(typename 
   const int nbody = dm.nbody, nu = dm.nu, nq = dm.nq, ngeom = dm.ngeom;
   const float h = dm.timestep;
   // diagnostic build only: shader-clock time per phase, summed over the substeps (never executed in the product kernel)
-  unsigned long long pt0 = 0, pacc[16], pext[8];   // pext: heightfield narrowphase: cycles in [0] sub-grids [1] probe passes [2] full-MPR batches; counts [3] work items [4] probe batches [5] probes run [6] full batches [7] full MPRs run
-  if (PROF) { for (int i = 0; i < 16; i++) pacc[i] = 0; for (int i = 0; i < 8; i++) pext[i] = 0; pt0 = __builtin_amdgcn_s_memtime(); }
+  unsigned long long pt0 = 0, pacc[16], pext[16];   // pext: heightfield narrowphase: cycles in [0] sub-grids [1] probe passes [2] full-MPR batches; counts [3] work items [4] probe batches [5] probes run [6] full batches [7] full MPRs run
+  if (PROF) { for (int i = 0; i < 16; i++) pacc[i] = 0; for (int i = 0; i < 16; i++) pext[i] = 0; pt0 = __builtin_amdgcn_s_memtime(); }
 #define PEXT_T0() unsigned long long pe0_ = 0; if (PROF) { __builtin_amdgcn_s_waitcnt(0); pe0_ = __builtin_amdgcn_s_memtime(); }
 #define PEXT_ADD(i) do { if (PROF) { __builtin_amdgcn_s_waitcnt(0); unsigned long long t_ = __builtin_amdgcn_s_memtime(); pext[i] += t_ - pe0_; pe0_ = t_; } } while (0)
 #define STAMP(i) do { KARGS_FENCE(); if (PROF) { __builtin_amdgcn_s_waitcnt(0); unsigned long long t_ = __builtin_amdgcn_s_memtime(); pacc[i] += t_ - pt0; pt0 = t_; } } while (0)
@@ -1447,6 +1447,7 @@ __global__ __launch_bounds__(64, (EPW == 2 ? 2 : (163840 / (int)sizeof(typename 
             // pairs with a convex hull: one at a time with all 64 lanes sharing the vertex scans (cosim_set_param "pair_mode" 0 runs them
             // lane-parallel, every lane scanning its own hulls: measured slower on the 700-vertex wheel hulls)
             mesh = cand && A.pair_coop && (G1.g_type == CS_GEOM_MESH || G2.g_type == CS_GEOM_MESH);
+            if (PROF) { const unsigned long long sm = __ballot(d2 <= rs * rs); if (ln == 0) pext[12] += __popcll(sm); }   // pairs past the bounding spheres
             if constexpr ((GTM & GT_BOX) != 0) boxes = cand && A.pair_boxbox && G1.g_type == CS_GEOM_BOX && G2.g_type == CS_GEOM_BOX;
           }
           bool hit = false;
@@ -1493,7 +1494,11 @@ __global__ __launch_bounds__(64, (EPW == 2 ? 2 : (163840 / (int)sizeof(typename 
               make_cobj(o2, h2);
               const MprPair<GTM, true> sup{o1, o2, HG, ln};
               float dep2 = 0.f, n2[3] = {0.f, 0.f, 1.f}, c2[3] = {0.f, 0.f, 0.f};
-              const bool hit2 = mpr_penetration(sup, o1.center, o2.center, dep2, n2, c2) && (n2[0] != 0.f || n2[1] != 0.f || n2[2] != 0.f);
+              int nit2 = 0;
+              unsigned long long tm0_ = 0;
+              if (PROF) tm0_ = __builtin_amdgcn_s_memtime();
+              const bool hit2 = mpr_penetration(sup, o1.center, o2.center, dep2, n2, c2, PROF ? &nit2 : nullptr) && (n2[0] != 0.f || n2[1] != 0.f || n2[2] != 0.f);
+              if (PROF) { pext[8] += 1; pext[9] += hit2 ? 1 : 0; pext[10] += nit2; pext[11] += __builtin_amdgcn_s_memtime() - tm0_; }   // hull pairs: run, hit, refinement iterations, cycles
               if (hit2) {
                 if (ln == 0) pair_put(CT ? npc : ncon, -dep2, h2 | ((h1 + 1) << 8), c2, n2);
                 if constexpr (CT) npc++; else ncon++;
@@ -2484,7 +2489,7 @@ __global__ __launch_bounds__(64, (EPW == 2 ? 2 : (163840 / (int)sizeof(typename 
   if (PROF && A.dbg != nullptr && wlane == 0)
   {
     for (int i = 0; i < 16; i++) atomicAdd(reinterpret_cast<unsigned long long*>(A.dbg) + i, pacc[i]);
-    for (int i = 0; i < 8; i++) atomicAdd(reinterpret_cast<unsigned long long*>(A.dbg) + 16 + i, pext[i]);
+    for (int i = 0; i < 16; i++) atomicAdd(reinterpret_cast<unsigned long long*>(A.dbg) + 16 + i, pext[i]);
   }
   if (lane < nq) rec[lay.s_qpos + lane] = S.qpos[lane];
   if (lane < NV) { rec[lay.s_qvel + lane] = S.qvel[lane]; rec[lay.s_warm + lane] = S.qacc[lane]; }

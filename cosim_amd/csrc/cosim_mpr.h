@@ -90,19 +90,32 @@ __device__ __forceinline__ void cobj_support(const CObj& o, const HullGraph& H, 
     const float* v = hull + 3 * (o.adr + bi);
     r[0] = v[0]; r[1] = v[1]; r[2] = v[2];
   } else if (COOP && (GTM & GT_MESH) && o.kind == CS_GEOM_MESH) {
+    // all 64 lanes share one scan.  COOP_K vertices per lane are in flight per trip (a dependent trip per vertex made a 696-vertex
+    // wheel hull cost eleven memory latencies per support query); the wave-wide maximum and its lowest index come from DPP minima
+    // (the index as a float: exact below 2^24), not from six LDS-crossbar shuffles.
+    constexpr int COOP_K = 4;
+    const int num = __builtin_amdgcn_readfirstlane(o.num);
+    const float* v0 = hull + 3 * (size_t)__builtin_amdgcn_readfirstlane(o.adr);
     float best = -3.0e38f;
     int besti = 0x7fffffff;
-    for (int i = ln; i < o.num; i += 64) {
-      const float* v = hull + 3 * (o.adr + i);
-      const float t = l[0] * v[0] + l[1] * v[1] + l[2] * v[2];
-      if (t > best) { best = t; besti = i; }
+    for (int i0 = 0; i0 < num; i0 += 64 * COOP_K) {
+      float x[COOP_K][3];
+#pragma unroll
+      for (int k = 0; k < COOP_K; k++) {
+        const float* v = v0 + 3 * min(i0 + ln + 64 * k, num - 1);
+        x[k][0] = v[0]; x[k][1] = v[1]; x[k][2] = v[2];
+      }
+#pragma unroll
+      for (int k = 0; k < COOP_K; k++) {
+        const int i = i0 + ln + 64 * k;
+        const float t = l[0] * x[k][0] + l[1] * x[k][1] + l[2] * x[k][2];
+        if (i < num && t > best) { best = t; besti = i; }
+      }
     }
     const float bmax = -wave_min(-best);
-    int bi = (best == bmax) ? besti : 0x7fffffff;   // lowest index among ties, like a sequential scan
-#pragma unroll
-    for (int s = 32; s > 0; s >>= 1) bi = min(bi, __shfl_xor(bi, s, 64));
-    if (bi >= o.num) bi = 0;
-    const float* v = hull + 3 * (o.adr + bi);
+    int bi = (int)wave_min(best == bmax ? (float)besti : 3.0e38f);   // lowest index among ties, like a sequential scan
+    if (bi >= num || bi < 0) bi = 0;
+    const float* v = v0 + 3 * bi;
     r[0] = v[0]; r[1] = v[1]; r[2] = v[2];
   } else if ((GTM & GT_SPHERE) && o.kind == CS_GEOM_SPHERE) {
     r[0] = l[0] * o.size[0]; r[1] = l[1] * o.size[0]; r[2] = l[2] * o.size[0];

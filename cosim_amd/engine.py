@@ -243,7 +243,7 @@ class Engine:
         return out
 
     def profile_step(self, actions_ptr, commands_ptr, state_out_ptr, term_ptr, trunc_ptr) -> np.ndarray:
-        out = np.zeros(24, dtype=np.float64)
+        out = np.zeros(32, dtype=np.float64)
         self._check(self.L.cosim_profile_step(self.h, actions_ptr, commands_ptr, state_out_ptr, term_ptr, trunc_ptr, out.ctypes.data))
         return out
 

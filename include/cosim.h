@@ -127,10 +127,10 @@ int cosim_debug_forward(cosim_engine_t* e, int env, const char* name, float* hos
  * the number of launches averaged; resets the accumulator. */
 int cosim_kernel_time(cosim_engine_t* e, float* avg_ms, int* launches);
 int cosim_set_timing(cosim_engine_t* e, int enabled);
-/* Diagnostic build of the step kernel with s_memtime stamps at phase boundaries (flamingo_light_v1 flat only): one control
- * step; cycles_out16 must hold 24 doubles: [i < 16] = mean shader-clock cycles per env spent in phase i, [16..23] = the heightfield
- * narrowphase's split (cycles in sub-grid setup / probe passes / full-MPR batches, then counts: work items, probe batches, probes run,
- * full batches, full MPRs run), see tools/gpu_phases.py.  Never timed. */
+/* Diagnostic build of the step kernel with s_memtime stamps at phase boundaries (one variant per bench workload): one control
+ * step; cycles_out16 must hold 32 doubles: [i < 16] = mean shader-clock cycles per env spent in phase i, [16..23] = the heightfield
+ * narrowphase's split (flat kernels: robot-robot pairs, contact-matrix accumulation, tree pass), [24..28] = hull pairs: MPR runs,
+ * hits, refinement iterations, cycles, pairs past the bounding spheres; see tools/gpu_phases.py.  Never timed. */
 int cosim_profile_step(cosim_engine_t* e, const float* actions_dev, const float* commands_dev, float* state_out_dev,
                        uint8_t* terminated_dev, uint8_t* truncated_dev, double* cycles_out16);
 

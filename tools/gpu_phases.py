@@ -25,7 +25,7 @@ env.reset()
 for t in range(settle):
     env.step(acts[t])
 torch.cuda.synchronize()
-acc = np.zeros(24)
+acc = np.zeros(32)
 for t in range(settle, settle + K):
     a = acts[t].contiguous()
     acc += env.engine.profile_step(a.data_ptr(), env._cmd_ptr(), env.state.data_ptr(), env.terminated.data_ptr(), env.truncated.data_ptr())
@@ -48,3 +48,7 @@ if acc[19] > 0:
 elif acc[16] > 0:
     print(f"  robot-robot pairs (broadphase + MPR): {acc[16]:.0f} cycles = {100*acc[16]/tot:.1f} % of the step")
     print(f"  contact-twist Hessian: per-body matrices {acc[17]:.0f} cycles ({100*acc[17]/tot:.1f} %), tree pass {acc[18]:.0f} cycles ({100*acc[18]/tot:.1f} %)")
+if acc[24] > 0:
+    sub = int(env.cm.blob.frame_skip)
+    print(f"  robot-robot pairs with a hull, per substep: {acc[28]/sub:.1f} past the bounding spheres, {acc[24]/sub:.2f} MPR runs ({acc[25]/sub:.2f} hits), "
+          f"{acc[26]/max(acc[24],1):.1f} refinement iterations per run, {acc[27]/max(acc[24],1):.0f} cycles per run ({acc[27]:.0f} per step = {100*acc[27]/tot:.1f} %)")
