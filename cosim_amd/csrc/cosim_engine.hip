@@ -466,12 +466,14 @@ int cosim_create(const cosim_model_t* model, const float* hull_vert, const int* 
   HIP_TRY(hipMalloc(&e->d_params, (size_t)n_envs * e->lay.p_stride * sizeof(float)));
   HIP_TRY(hipMalloc(&e->d_dbg, 8192 * sizeof(float)));
   int nhv = model->nhullvert > 0 ? model->nhullvert : 1, nhe = model->nhulledge > 0 ? model->nhulledge : 1;
-  HIP_TRY(hipMalloc(&e->d_hull_vert, (size_t)nhv * 3 * sizeof(float)));
+  HIP_TRY(hipMalloc(&e->d_hull_vert, (size_t)nhv * 4 * sizeof(float)));   // 16 bytes per vertex on the device: one load each
   HIP_TRY(hipMalloc(&e->d_hull_adr, (size_t)(nhv + 1) * sizeof(int)));
   HIP_TRY(hipMalloc(&e->d_hull_nbr, (size_t)nhe * sizeof(int)));
   if (model->nhullvert > 0) {
     if (!hull_vert || !hull_adr || !hull_nbr) return fail(COSIM_EINVAL, "cosim_create: model has mesh geoms but no hull arrays were passed");
-    HIP_TRY(hipMemcpy(e->d_hull_vert, hull_vert, (size_t)model->nhullvert * 3 * sizeof(float), hipMemcpyHostToDevice));
+    std::vector<float> hv4((size_t)model->nhullvert * 4, 0.f);
+    for (int i = 0; i < model->nhullvert; i++) for (int k = 0; k < 3; k++) hv4[4 * (size_t)i + k] = hull_vert[3 * (size_t)i + k];
+    HIP_TRY(hipMemcpy(e->d_hull_vert, hv4.data(), hv4.size() * sizeof(float), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(e->d_hull_adr, hull_adr, (size_t)(model->nhullvert + 1) * sizeof(int), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(e->d_hull_nbr, hull_nbr, (size_t)model->nhulledge * sizeof(int), hipMemcpyHostToDevice));
   }

@@ -1303,7 +1303,7 @@ __global__ __launch_bounds__(64, (EPW == 2 ? 2 : (163840 / (int)sizeof(typename 
                   for (int k = 0; k < 3; k++) { S.cpos[ncon][k] = pos[k]; S.cnrm[NRM ? ncon : 0][k] = n[k]; }
                 }
                 ncon++;
-              });
+              }, PROF ? pext + 8 : nullptr);   // heightfield kernels: [24..29] = cooperative walk: box cycles, MPR runs, MPR cycles, geoms, hits, refinement iterations
             }
           }
         }
@@ -1330,16 +1330,24 @@ __global__ __launch_bounds__(64, (EPW == 2 ? 2 : (163840 / (int)sizeof(typename 
           const float offn = n[0] * (gxp[0] - P0[0]) + n[1] * (gxp[1] - P0[1]) + n[2] * (gxp[2] - P0[2]);
           float best = 3.0e38f;
           int besti = 0x7fffffff;
-          for (int i = ln; i < num; i += LW) {
-            const float* v = A.hull_vert + 3 * (adr + i);
-            const float dist = offn + lnv[0] * v[0] + lnv[1] * v[1] + lnv[2] * v[2];
-            if (dist < best) { best = dist; besti = i; }
+          {
+            // four vertices per lane in flight per trip (16 bytes per vertex: one load each)
+            const float4* hv = reinterpret_cast<const float4*>(A.hull_vert) + adr;
+            for (int i0 = 0; i0 < num; i0 += 4 * LW) {
+              float4 x[4];
+#pragma unroll
+              for (int k = 0; k < 4; k++) x[k] = hv[min(i0 + ln + LW * k, num - 1)];
+#pragma unroll
+              for (int k = 0; k < 4; k++) {
+                const int i = i0 + ln + LW * k;
+                const float dist = offn + lnv[0] * x[k].x + lnv[1] * x[k].y + lnv[2] * x[k].z;
+                if (i < num && dist < best) { best = dist; besti = i; }
+              }
+            }
           }
           const float bmin = grp_min<LW>(best);
           if (!(bmin <= gmargin)) continue;
-          int bi = (best == bmin) ? besti : 0x7fffffff;  // lowest vertex index among ties, like a sequential scan
-#pragma unroll
-          for (int o = LW / 2; o > 0; o >>= 1) bi = min(bi, __shfl_xor(bi, o, 64));
+          const int bi = (int)grp_min<LW>(best == bmin ? (float)besti : 3.0e38f);  // lowest vertex index among ties, like a sequential scan
           // candidates of mjc_PlaneConvex: the support vertex (candidate 0), then its hull neighbours in list order; the
           // first four within the margin become contacts.  One lane per candidate: one round of dependent loads, not a
           // serial walk that the whole wave would wait on.
@@ -1351,7 +1359,8 @@ __global__ __launch_bounds__(64, (EPW == 2 ? 2 : (163840 / (int)sizeof(typename 
             float dist = 0.f, cpw[3] = {0.f, 0.f, 0.f};
             if (cand < nnb + 1) {
               const int i = cand == 0 ? bi : A.hull_nbr[lo + cand - 1];
-              const float* v = A.hull_vert + 3 * (adr + i);
+              const float4 v4 = reinterpret_cast<const float4*>(A.hull_vert)[adr + i];
+              const float v[3] = {v4.x, v4.y, v4.z};
               dist = offn + lnv[0] * v[0] + lnv[1] * v[1] + lnv[2] * v[2];
               okc = !(dist > gmargin);
               const float w[3] = {m[0] * v[0] + m[1] * v[1] + m[2] * v[2], m[3] * v[0] + m[4] * v[1] + m[5] * v[2], m[6] * v[0] + m[7] * v[1] + m[8] * v[2]};
@@ -1447,7 +1456,7 @@ __global__ __launch_bounds__(64, (EPW == 2 ? 2 : (163840 / (int)sizeof(typename 
             // pairs with a convex hull: one at a time with all 64 lanes sharing the vertex scans (cosim_set_param "pair_mode" 0 runs them
             // lane-parallel, every lane scanning its own hulls: measured slower on the 700-vertex wheel hulls)
             mesh = cand && A.pair_coop && (G1.g_type == CS_GEOM_MESH || G2.g_type == CS_GEOM_MESH);
-            if (PROF) { const unsigned long long sm = __ballot(d2 <= rs * rs); if (ln == 0) pext[12] += __popcll(sm); }   // pairs past the bounding spheres
+            if (PROF && !HF) { const unsigned long long sm = __ballot(d2 <= rs * rs); if (ln == 0) pext[12] += __popcll(sm); }   // pairs past the bounding spheres
             if constexpr ((GTM & GT_BOX) != 0) boxes = cand && A.pair_boxbox && G1.g_type == CS_GEOM_BOX && G2.g_type == CS_GEOM_BOX;
           }
           bool hit = false;
@@ -1498,7 +1507,7 @@ __global__ __launch_bounds__(64, (EPW == 2 ? 2 : (163840 / (int)sizeof(typename 
               unsigned long long tm0_ = 0;
               if (PROF) tm0_ = __builtin_amdgcn_s_memtime();
               const bool hit2 = mpr_penetration(sup, o1.center, o2.center, dep2, n2, c2, PROF ? &nit2 : nullptr) && (n2[0] != 0.f || n2[1] != 0.f || n2[2] != 0.f);
-              if (PROF) { pext[8] += 1; pext[9] += hit2 ? 1 : 0; pext[10] += nit2; pext[11] += __builtin_amdgcn_s_memtime() - tm0_; }   // hull pairs: run, hit, refinement iterations, cycles
+              if (PROF && !HF) { pext[8] += 1; pext[9] += hit2 ? 1 : 0; pext[10] += nit2; pext[11] += __builtin_amdgcn_s_memtime() - tm0_; }   // hull pairs: run, hit, refinement iterations, cycles
               if (hit2) {
                 if (ln == 0) pair_put(CT ? npc : ncon, -dep2, h2 | ((h1 + 1) << 8), c2, n2);
                 if constexpr (CT) npc++; else ncon++;

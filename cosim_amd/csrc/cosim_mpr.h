@@ -74,49 +74,49 @@ __device__ __forceinline__ void cobj_support(const CObj& o, const HullGraph& H, 
       const int src = __builtin_ctzll(pm);   // a lane that still waits: its hull is served now
       const int adr_u = __builtin_amdgcn_readlane(o.adr, src), num_u = __builtin_amdgcn_readlane(o.num, src);
       const bool mine = pending && o.adr == adr_u;
-      const float* v0 = hull + 3 * (size_t)adr_u;
+      const float4* v0 = reinterpret_cast<const float4*>(hull) + adr_u;
       for (int i = 0; i < num_u; i += 4) {
-        float x[12];
+        float4 x[4];
 #pragma unroll
-        for (int k = 0; k < 12; k++) x[k] = v0[min(3 * i + k, 3 * num_u - 1)];
+        for (int k = 0; k < 4; k++) x[k] = v0[min(i + k, num_u - 1)];
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-          const float t = l[0] * x[3 * k] + l[1] * x[3 * k + 1] + l[2] * x[3 * k + 2];
+          const float t = l[0] * x[k].x + l[1] * x[k].y + l[2] * x[k].z;
           if (mine && i + k < num_u && t > best) { best = t; bi = i + k; }
         }
       }
       if (mine) pending = false;
     }
-    const float* v = hull + 3 * (o.adr + bi);
-    r[0] = v[0]; r[1] = v[1]; r[2] = v[2];
+    const float4 v = reinterpret_cast<const float4*>(hull)[o.adr + bi];
+    r[0] = v.x; r[1] = v.y; r[2] = v.z;
   } else if (COOP && (GTM & GT_MESH) && o.kind == CS_GEOM_MESH) {
-    // all 64 lanes share one scan.  COOP_K vertices per lane are in flight per trip (a dependent trip per vertex made a 696-vertex
+    // all 64 lanes share one scan over the hull (16 bytes per vertex: one load each).  COOP_K vertices per lane are in flight per trip (a dependent trip per vertex made a 696-vertex
     // wheel hull cost eleven memory latencies per support query); the wave-wide maximum and its lowest index come from DPP minima
     // (the index as a float: exact below 2^24), not from six LDS-crossbar shuffles.
-    constexpr int COOP_K = 4;
+    constexpr int COOP_K = 6;
     const int num = __builtin_amdgcn_readfirstlane(o.num);
-    const float* v0 = hull + 3 * (size_t)__builtin_amdgcn_readfirstlane(o.adr);
-    float best = -3.0e38f;
+    const float4* v0 = reinterpret_cast<const float4*>(hull) + __builtin_amdgcn_readfirstlane(o.adr);
+    float best = -3.0e38f, bx = 0.f, by = 0.f, bz = 0.f;
     int besti = 0x7fffffff;
     for (int i0 = 0; i0 < num; i0 += 64 * COOP_K) {
-      float x[COOP_K][3];
+      float4 x[COOP_K];
 #pragma unroll
-      for (int k = 0; k < COOP_K; k++) {
-        const float* v = v0 + 3 * min(i0 + ln + 64 * k, num - 1);
-        x[k][0] = v[0]; x[k][1] = v[1]; x[k][2] = v[2];
-      }
+      for (int k = 0; k < COOP_K; k++) x[k] = v0[min(i0 + ln + 64 * k, num - 1)];
 #pragma unroll
       for (int k = 0; k < COOP_K; k++) {
         const int i = i0 + ln + 64 * k;
-        const float t = l[0] * x[k][0] + l[1] * x[k][1] + l[2] * x[k][2];
-        if (i < num && t > best) { best = t; besti = i; }
+        const float t = l[0] * x[k].x + l[1] * x[k].y + l[2] * x[k].z;
+        if (i < num && t > best) { best = t; besti = i; bx = x[k].x; by = x[k].y; bz = x[k].z; }
       }
     }
+    // the winner's coordinates come out of its lane's registers (vertex i lives in lane i & 63), not from a dependent load; one lane
+    // at the maximum is the usual case, ties take the lowest index like a sequential scan
     const float bmax = -wave_min(-best);
-    int bi = (int)wave_min(best == bmax ? (float)besti : 3.0e38f);   // lowest index among ties, like a sequential scan
-    if (bi >= num || bi < 0) bi = 0;
-    const float* v = v0 + 3 * bi;
-    r[0] = v[0]; r[1] = v[1]; r[2] = v[2];
+    const unsigned long long tm = __ballot(best == bmax);
+    int src = __builtin_ctzll(tm);
+    if (tm & (tm - 1)) src = ((int)wave_min(best == bmax ? (float)besti : 3.0e38f)) & 63;
+    src = __builtin_amdgcn_readfirstlane(src);
+    r[0] = rl(bx, src); r[1] = rl(by, src); r[2] = rl(bz, src);
   } else if ((GTM & GT_SPHERE) && o.kind == CS_GEOM_SPHERE) {
     r[0] = l[0] * o.size[0]; r[1] = l[1] * o.size[0]; r[2] = l[2] * o.size[0];
   } else if ((GTM & GT_CYLINDER) && o.kind == CS_GEOM_CYLINDER) {
@@ -129,6 +129,55 @@ __device__ __forceinline__ void cobj_support(const CObj& o, const HullGraph& H, 
   float w[3];
   qrot(w, o.q, r);
   out[0] = o.pos[0] + w[0]; out[1] = o.pos[1] + w[1]; out[2] = o.pos[2] + w[2];
+}
+
+// The six support queries along +-x, +-y, +-z of a hull (its exact axis-aligned box) as ONE cooperative scan: three dot products per
+// vertex serve all six arg-maxima, with the same comparisons, tie rule and final rotation as six cobj_support calls (same bits).
+__device__ __forceinline__ void cobj_box_coop(const CObj& o, const HullGraph& H, float* lo, float* hi, int ln) {
+  const float qi[4] = {o.q[0], -o.q[1], -o.q[2], -o.q[3]};
+  float l[3][3];
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    float d[3] = {0.f, 0.f, 0.f};
+    d[k] = 1.f;
+    qrot(l[k], qi, d);
+  }
+  const int num = __builtin_amdgcn_readfirstlane(o.num);
+  const float4* v0 = reinterpret_cast<const float4*>(H.vert) + __builtin_amdgcn_readfirstlane(o.adr);
+  float best[6], bv[6][3];
+  int besti[6];
+#pragma unroll
+  for (int s = 0; s < 6; s++) { best[s] = -3.0e38f; besti[s] = 0x7fffffff; bv[s][0] = bv[s][1] = bv[s][2] = 0.f; }
+  for (int i0 = 0; i0 < num; i0 += 64 * 4) {
+    float4 x[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) x[k] = v0[min(i0 + ln + 64 * k, num - 1)];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const int i = i0 + ln + 64 * k;
+#pragma unroll
+      for (int a = 0; a < 3; a++) {
+        // the query along -e_a rotates to exactly -l[a] (qrot is odd in its vector argument), whose dot products are exactly -t
+        const float t = l[a][0] * x[k].x + l[a][1] * x[k].y + l[a][2] * x[k].z;
+        if (i < num && t > best[2 * a]) { best[2 * a] = t; besti[2 * a] = i; bv[2 * a][0] = x[k].x; bv[2 * a][1] = x[k].y; bv[2 * a][2] = x[k].z; }
+        const float u = -t;
+        if (i < num && u > best[2 * a + 1]) { best[2 * a + 1] = u; besti[2 * a + 1] = i; bv[2 * a + 1][0] = x[k].x; bv[2 * a + 1][1] = x[k].y; bv[2 * a + 1][2] = x[k].z; }
+      }
+    }
+  }
+#pragma unroll
+  for (int s = 0; s < 6; s++) {
+    const float bmax = -wave_min(-best[s]);
+    const unsigned long long tm = __ballot(best[s] == bmax);
+    int src = __builtin_ctzll(tm);
+    if (tm & (tm - 1)) src = ((int)wave_min(best[s] == bmax ? (float)besti[s] : 3.0e38f)) & 63;
+    src = __builtin_amdgcn_readfirstlane(src);
+    const float r[3] = {rl(bv[s][0], src), rl(bv[s][1], src), rl(bv[s][2], src)};
+    float w[3];
+    qrot(w, o.q, r);
+    const int a = s >> 1;
+    if (s & 1) lo[a] = o.pos[a] + w[a]; else hi[a] = o.pos[a] + w[a];
+  }
 }
 
 template <int GTM, bool COOP>
@@ -388,23 +437,29 @@ struct MprPrismGeom {
 // base's offset on the field in fp64.  emit(dist, pos, normal) is called once per penetrated prism, in strip order.
 template <int GTM, bool COOP, class EMIT>
 __device__ __forceinline__ void hfield_geom(const Terrain& T, const CObj& o, const float* ctr, float rb, float margin, float base,
-                                            const HullGraph& hull, int ln, const EMIT& emit) {
+                                            const HullGraph& hull, int ln, const EMIT& emit, unsigned long long* prof = nullptr) {
   // box-sphere early outs
+  unsigned long long pt_ = 0;
+  if (prof) pt_ = __builtin_amdgcn_s_memtime();
   const double lx = (double)ctr[0] + T.ox, ly = (double)ctr[1] + T.oy;
   if ((double)T.sx < lx - rb - margin || -(double)T.sx > lx + rb + margin || (double)T.sy < ly - rb - margin || -(double)T.sy > ly + rb + margin) return;
   if (T.sz < ctr[2] - T.gz - rb - margin || -base > ctr[2] - T.gz + rb + margin) return;
   // axis-aligned box of the geom through its support function
   float lo[3], hi[3];
+  if constexpr (COOP) cobj_box_coop(o, hull, lo, hi, ln);
+  else {
 #pragma unroll
-  for (int k = 0; k < 3; k++) {
-    float d[3] = {0.f, 0.f, 0.f}, p[3];
-    d[k] = 1.f;
-    cobj_support<GTM, COOP>(o, hull, d, p, ln);
-    hi[k] = p[k];
-    d[k] = -1.f;
-    cobj_support<GTM, COOP>(o, hull, d, p, ln);
-    lo[k] = p[k];
+    for (int k = 0; k < 3; k++) {
+      float d[3] = {0.f, 0.f, 0.f}, p[3];
+      d[k] = 1.f;
+      cobj_support<GTM, COOP>(o, hull, d, p, ln);
+      hi[k] = p[k];
+      d[k] = -1.f;
+      cobj_support<GTM, COOP>(o, hull, d, p, ln);
+      lo[k] = p[k];
+    }
   }
+  if (prof) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); prof[0] += t_ - pt_; prof[3] += 1; }
   const double x0 = (double)lo[0] + T.ox, x1 = (double)hi[0] + T.ox, y0 = (double)lo[1] + T.oy, y1 = (double)hi[1] + T.oy;
   if (x0 - margin > T.sx || x1 + margin < -T.sx || y0 - margin > T.sy || y1 + margin < -T.sy || lo[2] - T.gz - margin > T.sz ||
       hi[2] - T.gz + margin < -base) return;
@@ -433,7 +488,11 @@ __device__ __forceinline__ void hfield_geom(const Terrain& T, const CObj& o, con
                              (P.zt[0] + P.zt[1] + P.zt[2] + 3.f * P.zb) * (1.f / 6.f)};
         const MprPrismGeom<GTM, COOP> sup{P, o, hull, ln};
         float depth = 0.f, n[3] = {0.f, 0.f, 1.f}, pos[3] = {0.f, 0.f, 0.f};
-        if (mpr_penetration(sup, c1, o.center, depth, n, pos) && (n[0] != 0.f || n[1] != 0.f || n[2] != 0.f)) {
+        int nit_ = 0;
+        if (prof) pt_ = __builtin_amdgcn_s_memtime();
+        const bool hit_ = mpr_penetration(sup, c1, o.center, depth, n, pos, prof ? &nit_ : nullptr) && (n[0] != 0.f || n[1] != 0.f || n[2] != 0.f);
+        if (prof) { prof[1] += 1; prof[2] += __builtin_amdgcn_s_memtime() - pt_; prof[4] += hit_ ? 1 : 0; prof[5] += nit_; }
+        if (hit_) {
           emit(margin - depth, pos, n);
           cnt++;
         }

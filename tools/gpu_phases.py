@@ -40,7 +40,7 @@ print(f"{wl}: mean wave lifetime {tot:.0f} cycles per control step ({int(env.cm.
 for i in list(range(10)) + [10, 11, 12, 13, 14, 15]:
     print(f"  {names[i]:46s} {acc[i]:12.0f} cycles  {100*acc[i]/tot:5.1f} %")
 if acc[19] > 0:
-    print(f"  (robot-robot pairs = collision - prism walk: {acc[5]-acc[16]-acc[17]-acc[18]:.0f} cycles per step)")
+    print(f"  (collision - staged prism walk = cooperative hull walk + robot-robot pairs: {acc[5]-acc[16]-acc[17]-acc[18]:.0f} cycles per step)")
     sub = int(env.cm.blob.frame_skip)
     print(f"  heightfield narrowphase per substep: slowest-lane MPR iterations summed over full batches {acc[19]/sub:.0f}, {acc[20]/sub:.1f} probe batches, "
           f"{acc[22]/sub:.1f} full-MPR batches (inside mpr_penetration {acc[21]/sub:.0f} cycles, set-up before it {acc[23]/sub:.0f}); cycles: sub-grids {acc[16]/sub:.0f}, probe passes {acc[17]/sub:.0f}, "
@@ -48,7 +48,11 @@ if acc[19] > 0:
 elif acc[16] > 0:
     print(f"  robot-robot pairs (broadphase + MPR): {acc[16]:.0f} cycles = {100*acc[16]/tot:.1f} % of the step")
     print(f"  contact-twist Hessian: per-body matrices {acc[17]:.0f} cycles ({100*acc[17]/tot:.1f} %), tree pass {acc[18]:.0f} cycles ({100*acc[18]/tot:.1f} %)")
-if acc[24] > 0:
-    sub = int(env.cm.blob.frame_skip)
+sub = int(env.cm.blob.frame_skip)
+if acc[19] > 0 and acc[27] > 0:
+    print(f"  cooperative hull walk per substep: {acc[27]/sub:.1f} geoms, exact boxes {acc[24]/sub:.0f} cycles, {acc[25]/sub:.1f} MPR runs ({acc[28]/sub:.2f} hits, "
+          f"{acc[29]/max(acc[25],1):.1f} refinement iterations per run), {acc[26]/max(acc[25],1):.0f} cycles per run; MPR {acc[26]:.0f} + boxes {acc[24]:.0f} cycles per step = "
+          f"{100*(acc[26]+acc[24])/tot:.1f} %")
+elif acc[24] > 0:
     print(f"  robot-robot pairs with a hull, per substep: {acc[28]/sub:.1f} past the bounding spheres, {acc[24]/sub:.2f} MPR runs ({acc[25]/sub:.2f} hits), "
           f"{acc[26]/max(acc[24],1):.1f} refinement iterations per run, {acc[27]/max(acc[24],1):.0f} cycles per run ({acc[27]:.0f} per step = {100*acc[27]/tot:.1f} %)")
