@@ -161,7 +161,8 @@ __device__ __forceinline__ float grp_bcast(float v, int j, int hb) {   // value 
 }
 
 // ------------------------------------------------------------------------------------------------ small math
-__device__ __forceinline__ void qmul(float* r, const float* a, const float* b) {
+template <class PA, class PB>
+__device__ __forceinline__ void qmul(float* r, PA a, PB b) {
   float w = a[0] * b[0] - a[1] * b[1] - a[2] * b[2] - a[3] * b[3];
   float x = a[0] * b[1] + a[1] * b[0] + a[2] * b[3] - a[3] * b[2];
   float y = a[0] * b[2] - a[1] * b[3] + a[2] * b[0] + a[3] * b[1];
@@ -174,25 +175,29 @@ __device__ __forceinline__ void qnorm(float* q) {
   float s = rsqrtf(n);
   q[0] *= s; q[1] *= s; q[2] *= s; q[3] *= s;
 }
-__device__ __forceinline__ void q2m(float* m, const float* q) {
+template <class PQ>
+__device__ __forceinline__ void q2m(float* m, PQ q) {
   float q00 = q[0] * q[0], q01 = q[0] * q[1], q02 = q[0] * q[2], q03 = q[0] * q[3], q11 = q[1] * q[1], q12 = q[1] * q[2],
         q13 = q[1] * q[3], q22 = q[2] * q[2], q23 = q[2] * q[3], q33 = q[3] * q[3];
   m[0] = q00 + q11 - q22 - q33; m[4] = q00 - q11 + q22 - q33; m[8] = q00 - q11 - q22 + q33;
   m[1] = 2.f * (q12 - q03); m[2] = 2.f * (q13 + q02); m[3] = 2.f * (q12 + q03);
   m[5] = 2.f * (q23 - q01); m[6] = 2.f * (q13 - q02); m[7] = 2.f * (q23 + q01);
 }
-__device__ __forceinline__ void qrot(float* r, const float* q, const float* v) {  // r = R(q) v
+template <class PQ, class PV>
+__device__ __forceinline__ void qrot(float* r, PQ q, PV v) {  // r = R(q) v (templates: model constants live in the constant address space)
   float m[9];
   q2m(m, q);
   float x = m[0] * v[0] + m[1] * v[1] + m[2] * v[2], y = m[3] * v[0] + m[4] * v[1] + m[5] * v[2],
         z = m[6] * v[0] + m[7] * v[1] + m[8] * v[2];
   r[0] = x; r[1] = y; r[2] = z;
 }
-__device__ __forceinline__ void cross(float* r, const float* a, const float* b) {
+template <class PA, class PB>
+__device__ __forceinline__ void cross(float* r, PA a, PB b) {
   float x = a[1] * b[2] - a[2] * b[1], y = a[2] * b[0] - a[0] * b[2], z = a[0] * b[1] - a[1] * b[0];
   r[0] = x; r[1] = y; r[2] = z;
 }
-__device__ __forceinline__ float dot3(const float* a, const float* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+template <class PA, class PB>
+__device__ __forceinline__ float dot3(PA a, PB b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
 __device__ __forceinline__ void mul_inert(float* res, const float* i, const float* v) {  // mju_mulInertVec
   res[0] = i[0] * v[0] + i[3] * v[1] + i[4] * v[2] - i[8] * v[4] + i[7] * v[5];
   res[1] = i[3] * v[0] + i[1] * v[1] + i[5] * v[2] + i[8] * v[3] - i[6] * v[5];
@@ -403,8 +408,8 @@ __device__ __forceinline__ void chol_park(float (*Lm)[LD], const float (&a)[NV],
 // struct with the union of the three types' vectors spilled to scratch on both sides of the ballots.
 // GTM: geom types present in the model (bit 0 sphere, 1 cylinder, 2 box, 3 mesh): absent types cost no registers.
 constexpr int GT_SPHERE = 1, GT_CYLINDER = 2, GT_BOX = 4, GT_MESH = 8;
-template <int GTM>
-__device__ __forceinline__ int prim_plane_contacts(const LaneRec& R, const float* xq, const float* xp, const float* P0, const float* n,
+template <int GTM, class REC>
+__device__ __forceinline__ int prim_plane_contacts(const REC& R, const float* xq, const float* xp, const float* P0, const float* n,
                                                    float margin, float (*stage)[4]) {
   const int gt = R.g_type;
   float v[3], pos[3];
@@ -516,7 +521,8 @@ __device__ __forceinline__ float terrain_height(const Terrain& T, float x, float
 #include "cosim_boxbox.h"
 namespace cosim {
 // ------------------------------------------------------------------------------------------------ impedance (mj_makeImpedance)
-__device__ __forceinline__ float impedance(const float* solimp, float pos, float margin) {
+template <class PS>
+__device__ __forceinline__ float impedance(PS solimp, float pos, float margin) {
   float d0 = fminf(MAXIMP, fmaxf(MINIMP, solimp[0])), d1 = fminf(MAXIMP, fmaxf(MINIMP, solimp[1]));
   float width = fmaxf(0.f, solimp[2]), mid = fminf(MAXIMP, fmaxf(MINIMP, solimp[3])), power = fmaxf(1.f, solimp[4]);
   if (d0 == d1 || width <= MINVAL) return 0.5f * (d0 + d1);
@@ -577,7 +583,8 @@ __global__ __launch_bounds__(64, (EPW == 2 ? 2 : (163840 / (int)sizeof(typename 
   L& S = SS[EPW == 1 ? 0 : (wlane >> 5)];
   const int env = A.mode == MODE_DEBUG ? A.dbg_env : A.env_first + (int)blockIdx.x * EPW + (EPW == 1 ? 0 : (wlane >> 5));
   if (env >= A.n_envs) return;
-  const DevModel& dm = *A.dm;
+  typedef const DevModel __attribute__((address_space(4)))* DevModelP;   // the model never changes while a kernel runs: constant address space = invariant loads
+  const auto& dm = *(DevModelP)(unsigned long long)A.dm;
 #define ob (*A.ob)
 #define lay (A.lay)
   float* rec = A.state + (size_t)env * lay.s_stride;
@@ -645,7 +652,7 @@ __global__ __launch_bounds__(64, (EPW == 2 ? 2 : (163840 / (int)sizeof(typename 
     if (A.mode == MODE_STEP) {
       const bool delayed = (ob.action_delay_prob > u01(philox_first(k0, k1, step_count, 0u, g0, g1))) && has_prev;  // control_manager.py:15-23
       if (lane < nu) {
-        const LaneRec& R = dm.rec[lane];
+        const auto& R = dm.rec[lane];
         const float raw_action = A.actions[(size_t)env * nu + lane];
         S.act[lane] = raw_action;
         float filt = delayed ? rec[lay.s_delay + lane] : raw_action;
@@ -661,7 +668,7 @@ __global__ __launch_bounds__(64, (EPW == 2 ? 2 : (163840 / (int)sizeof(typename 
         float c = R.a_ctrllimited ? fminf(R.a_ctrlrange[1], fmaxf(R.a_ctrlrange[0], t)) : t;
         float f = R.a_gear * c;
         const int d = R.a_dof;
-        const LaneRec& RD = dm.rec[d];
+        const auto& RD = dm.rec[d];
         if (RD.d_frclimited) f = fminf(RD.d_frcrange[1], fmaxf(RD.d_frcrange[0], f));
         S.qact[d] = f;
       }
@@ -678,7 +685,7 @@ __global__ __launch_bounds__(64, (EPW == 2 ? 2 : (163840 / (int)sizeof(typename 
       STAMP(0);   // prologue / previous epilogue
       // =========================================================== mj_kinematics: level-synchronous over the tree
       {
-        const LaneRec& R = dm.rec[ln];
+        const auto& R = dm.rec[ln];
         const int b_level = ln < nbody ? R.b_level : -1;
         const int maxdepth = dm.maxdepth;
         // the joint's own rotation depends on this body's qpos only: one sincos per body ahead of the sweep, not one per level
@@ -739,7 +746,7 @@ __global__ __launch_bounds__(64, (EPW == 2 ? 2 : (163840 / (int)sizeof(typename 
 #pragma unroll
       for (int k = 0; k < 10; k++) cinert[k] = 0.f;
       {
-        const LaneRec& R = dm.rec[ln];
+        const auto& R = dm.rec[ln];
         float xip[3] = {0.f, 0.f, 0.f}, bmass = 0.f, ximat[9];
 #pragma unroll
         for (int k = 0; k < 9; k++) ximat[k] = 0.f;
@@ -760,7 +767,7 @@ __global__ __launch_bounds__(64, (EPW == 2 ? 2 : (163840 / (int)sizeof(typename 
         const float c0 = sx * inv, c1 = sy * inv, c2 = sz * inv;
         if (ln == 0) { S.com[0] = c0; S.com[1] = c1; S.com[2] = c2; }
         if (ln > 0 && ln < nbody) {
-          const float* I = R.b_inertia;
+          const auto* I = R.b_inertia;
           float dif[3] = {xip[0] - c0, xip[1] - c1, xip[2] - c2};
           float Rm[9];
 #pragma unroll
@@ -789,11 +796,11 @@ __global__ __launch_bounds__(64, (EPW == 2 ? 2 : (163840 / (int)sizeof(typename 
       float cd[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
       float qv = 0.f;
       {
-        const LaneRec& R = dm.rec[ln];
+        const auto& R = dm.rec[ln];
         if (ln < NV) {
           qv = S.qvel[ln];
           const int b = R.d_body;
-          const LaneRec& RB = dm.rec[b];
+          const auto& RB = dm.rec[b];
           const int jt = RB.b_jtype, k = ln - RB.b_dadr;
           if (jt == CS_JNT_FREE) {
             if (k < 3) cd[3 + k] = 1.f;
@@ -832,7 +839,7 @@ __global__ __launch_bounds__(64, (EPW == 2 ? 2 : (163840 / (int)sizeof(typename 
       }
       crb_all[9] = grp_sum<LW>((ln > 0 && ln < nbody) ? cinert[9] : 0.f);
       if (ln < NV) {
-        const LaneRec& R = dm.rec[ln];
+        const auto& R = dm.rec[ln];
         float crb[10];
         const unsigned sub = dm.rec[R.d_body].b_subtree;
 #pragma unroll
@@ -858,10 +865,10 @@ __global__ __launch_bounds__(64, (EPW == 2 ? 2 : (163840 / (int)sizeof(typename 
       STAMP(3);   // crb
       // =========================================================== mj_comVel + mj_rne (bias) + passive + smooth force
       if (ln < NV) {
-        const LaneRec& R = dm.rec[ln];
+        const auto& R = dm.rec[ln];
         // velocity of the parent chain just before this dof (free joint: rotations see the translational part only)
         float cv[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        const LaneRec& RB = dm.rec[R.d_body];
+        const auto& RB = dm.rec[R.d_body];
         const int jt = RB.b_jtype, k = ln - RB.b_dadr;
         float cdd[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         if (jt == CS_JNT_FREE) {
@@ -891,7 +898,7 @@ __global__ __launch_bounds__(64, (EPW == 2 ? 2 : (163840 / (int)sizeof(typename 
       WSYNC();
       float cfb_l[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // this body's inertial + Coriolis wrench (lane = body)
       if (ln > 0 && ln < nbody) {
-        const LaneRec& R = dm.rec[ln];
+        const auto& R = dm.rec[ln];
         float cvel_b[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         float cacc[6] = {0.f, 0.f, 0.f, -dm.gravity[0], -dm.gravity[1], -dm.gravity[2]};
         for (unsigned mk = R.b_dofmask; mk; mk &= mk - 1) {
@@ -919,7 +926,7 @@ __global__ __launch_bounds__(64, (EPW == 2 ? 2 : (163840 / (int)sizeof(typename 
 #pragma unroll
       for (int q = 0; q < 6; q += 3) grp_sum3<LW>(cfb_l[q], cfb_l[q + 1], cfb_l[q + 2], cfb_all[q], cfb_all[q + 1], cfb_all[q + 2]);
       if (ln < NV) {
-        const LaneRec& R = dm.rec[ln];
+        const auto& R = dm.rec[ln];
         const unsigned sub = dm.rec[R.d_body].b_subtree;
         float f[6];
 #pragma unroll
@@ -975,7 +982,7 @@ __global__ __launch_bounds__(64, (EPW == 2 ? 2 : (163840 / (int)sizeof(typename 
       const float* const hfdata_ = A.hfield;
       // world pose of geom g as a convex object (mesh: body frame, vertices in body coordinates; primitive: geom frame)
       auto make_cobj = [&](CObj& o, int g) __attribute__((always_inline)) {
-        const LaneRec& G = dm.rec[g];
+        const auto& G = dm.rec[g];
         const int gb = G.g_body;
         const float bq[4] = {S.xquat[gb][0], S.xquat[gb][1], S.xquat[gb][2], S.xquat[gb][3]};
         const float4 ge = gext_[g];
@@ -995,7 +1002,7 @@ __global__ __launch_bounds__(64, (EPW == 2 ? 2 : (163840 / (int)sizeof(typename 
         }
       };
       {
-        const LaneRec& R = dm.rec[ln];
+        const auto& R = dm.rec[ln];
         constexpr bool is_plane = !HF;
         Terrain T;
         T.data = hfdata_; T.nrow = dm.hfield_nrow; T.ncol = dm.hfield_ncol;
@@ -1286,7 +1293,7 @@ __global__ __launch_bounds__(64, (EPW == 2 ? 2 : (163840 / (int)sizeof(typename 
             // hulls with few prisms: wave-cooperative, one (geom, prism) at a time (hfield_geom: the same walk, sequential)
             for (unsigned long long cm_ = __ballot(coop_geom); cm_; cm_ &= cm_ - 1) {
               const int g = __builtin_ctzll(cm_);
-              const LaneRec& G = dm.rec[g];
+              const auto& G = dm.rec[g];
               CObj o;
               make_cobj(o, g);
               float gctr[3];
@@ -1312,7 +1319,7 @@ __global__ __launch_bounds__(64, (EPW == 2 ? 2 : (163840 / (int)sizeof(typename 
         while (mm) {
           const int g = __builtin_ctzll(mm);
           mm &= mm - 1;
-          const LaneRec& G = dm.rec[g];
+          const auto& G = dm.rec[g];
           const int gb = G.g_body, adr = G.g_hulladr, num = G.g_hullnum;
           float gq[4] = {S.xquat[gb][0], S.xquat[gb][1], S.xquat[gb][2], S.xquat[gb][3]}, m[9];
           q2m(m, gq);
@@ -1405,7 +1412,7 @@ __global__ __launch_bounds__(64, (EPW == 2 ? 2 : (163840 / (int)sizeof(typename 
           if (p < npair) {
             const unsigned pk = A.pairs[p];
             g1 = pk & 0xffffu; g2 = pk >> 16;
-            const LaneRec &G1 = dm.rec[g1], &G2 = dm.rec[g2];
+            const auto &G1 = dm.rec[g1], &G2 = dm.rec[g2];
             const float q1[4] = {S.xquat[G1.g_body][0], S.xquat[G1.g_body][1], S.xquat[G1.g_body][2], S.xquat[G1.g_body][3]};
             const float q2[4] = {S.xquat[G2.g_body][0], S.xquat[G2.g_body][1], S.xquat[G2.g_body][2], S.xquat[G2.g_body][3]};
             float v1[3], v2[3];
@@ -1421,7 +1428,7 @@ __global__ __launch_bounds__(64, (EPW == 2 ? 2 : (163840 / (int)sizeof(typename 
               q2m(m1, q1);
               q2m(m2, q2);
               for (int k = 0; k < 3; k++) dv[k] = (S.xpos[G2.g_body][k] + v2[k]) - (S.xpos[G1.g_body][k] + v1[k]);
-              auto radius = [](const float* m, const float* hf, const float* a) {
+              auto radius = [](const float* m, const auto* hf, const float* a) {
                 return hf[0] * fabsf(m[0] * a[0] + m[3] * a[1] + m[6] * a[2]) + hf[1] * fabsf(m[1] * a[0] + m[4] * a[1] + m[7] * a[2]) +
                        hf[2] * fabsf(m[2] * a[0] + m[5] * a[1] + m[8] * a[2]);
               };
@@ -1523,7 +1530,7 @@ __global__ __launch_bounds__(64, (EPW == 2 ? 2 : (163840 / (int)sizeof(typename 
       const int ne = 3 * dm.neq, nf = dm.nfric;
       int nl = 0;
       {  // joint limits: compaction over bodies
-        const LaneRec& R = dm.rec[ln];
+        const auto& R = dm.rec[ln];
         bool lo_v = false, hi_v = false;
         float dlo = 0.f, dhi = 0.f;
         if (ln > 0 && ln < nbody && R.b_jtype == CS_JNT_HINGE && R.j_limited) {
@@ -1587,7 +1594,7 @@ __global__ __launch_bounds__(64, (EPW == 2 ? 2 : (163840 / (int)sizeof(typename 
           if (row < ne) {
             rtype[rr] = RT_EQ;
             const int e = row / 3, comp = row - 3 * e;
-            const LaneRec& E = dm.rec[e];
+            const auto& E = dm.rec[e];
             const int b1 = E.e_body1, b2 = E.e_body2;
             dir[0] = comp == 0 ? 1.f : 0.f; dir[1] = comp == 1 ? 1.f : 0.f; dir[2] = comp == 2 ? 1.f : 0.f;
             float p1[3], p2[3], v[3], q1[4] = {S.xquat[b1][0], S.xquat[b1][1], S.xquat[b1][2], S.xquat[b1][3]},
@@ -1606,7 +1613,7 @@ __global__ __launch_bounds__(64, (EPW == 2 ? 2 : (163840 / (int)sizeof(typename 
             rtype[rr] = RT_CONTACT;
             const int c = (row - ne) >> 2, edge = (row - ne) & 3;
             const int gg = con_geom<CT>(S, !CT, c, c), g = gg & 0xff, g1 = (gg >> 8) - 1;   // g1 < 0: geom1 is the ground (CT: dense rows are robot-robot contacts)
-            const LaneRec& G = dm.rec[g];
+            const auto& G = dm.rec[g];
             const int b = G.g_body, b1 = (SC && g1 >= 0) ? dm.rec[g1].g_body : 0;
             const float mu = (SC && g1 >= 0) ? fmaxf(MINMU, fmaxf(A.gext[g].w, A.gext[g1].w)) : S.p_gmu[g];
             const float* cn_ = con_nrm<CT, NRM>(S, !CT, c, c);
@@ -1645,7 +1652,7 @@ __global__ __launch_bounds__(64, (EPW == 2 ? 2 : (163840 / (int)sizeof(typename 
           if (row < ngen + nf) {
             rtype[rr] = RT_FRIC;
             rdof[rr] = dm.rec[row - ngen].d_fric;  // model-level list; a per-env value of zero leaves the row inert
-            const LaneRec& D = dm.rec[rdof[rr]];
+            const auto& D = dm.rec[rdof[rr]];
             rfloss[rr] = S.p_floss[rdof[rr]];
             rdiagA = S.p_dinvw[rdof[rr]];
             for (int k = 0; k < 2; k++) rsolref[k] = D.d_solref[k];
@@ -1655,7 +1662,7 @@ __global__ __launch_bounds__(64, (EPW == 2 ? 2 : (163840 / (int)sizeof(typename 
             rtype[rr] = RT_LIMIT;
             const int li = row - ngen - nf;
             const int b = S.lim_body[li];
-            const LaneRec& B = dm.rec[b];
+            const auto& B = dm.rec[b];
             rdof[rr] = B.b_dadr;
             rsign[rr] = S.lim_sign[li];
             rpos = S.lim_dist[li];
@@ -1718,7 +1725,7 @@ __global__ __launch_bounds__(64, (EPW == 2 ? 2 : (163840 / (int)sizeof(typename 
           if (c < ncon) {
             CGeo G;
             cgeo(c, G);
-            const LaneRec& GR = dm.rec[G.g];
+            const auto& GR = dm.rec[G.g];
             float vn, v1, v2, an, a1, a2;
             point_proj(S.tw[G.b], G, vn, v1, v2);
             point_proj(S.bw[G.b], G, an, a1, a2);
@@ -1987,7 +1994,7 @@ __global__ __launch_bounds__(64, (EPW == 2 ? 2 : (163840 / (int)sizeof(typename 
               // tree pass, straight into the row this lane factorises (only the lower triangle of H is read by the factorisation, and row
               // i's entries j <= i are exactly i's ancestors): y = (sum of the subtree's matrices) cdof_i, then a_row[j] += cdof_j . y
               if (ln < NV) {
-                const LaneRec& R = dm.rec[ln];
+                const auto& R = dm.rec[ln];
                 const unsigned sub = dm.rec[R.d_body].b_subtree & cbmask;
                 if (sub) {
                   float cdi[6], y[6];
@@ -2334,7 +2341,7 @@ __global__ __launch_bounds__(64, (EPW == 2 ? 2 : (163840 / (int)sizeof(typename 
           if (ln < NV) S.qvel[ln] = qv + h * qa;
           WSYNC();
           if (ln > 0 && ln < nbody) {
-            const LaneRec& R = dm.rec[ln];
+            const auto& R = dm.rec[ln];
             const int jt = R.b_jtype;
             if (jt == CS_JNT_HINGE) S.qpos[R.b_qadr] += h * S.qvel[R.b_dadr];
             else if (jt == CS_JNT_FREE) {
@@ -2389,7 +2396,7 @@ __global__ __launch_bounds__(64, (EPW == 2 ? 2 : (163840 / (int)sizeof(typename 
       if (lane == 0) { inf[0] = rmse; inf[1] = S.sens[7]; inf[2] = S.sens[8]; inf[3] = S.sens[6]; }
       if (lane < nu) { inf[4 + lane] = S.tq[lane]; inf[4 + nu + lane] = raw_action * dm.rec[lane].a_scale; }
       if (lane < dm.ninfo_state) {
-        const LaneRec& R = dm.rec[lane];
+        const auto& R = dm.rec[lane];
         inf[4 + 2 * nu + lane] = (R.i_kind == 0 ? S.qpos[R.i_adr] : S.qvel[R.i_adr]) * R.i_gear;
       }
     }
