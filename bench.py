@@ -145,11 +145,13 @@ def pmc_traffic(workload):
             vals[t[0]] = float(t[2]) * 1024.0                        # rocprofv3 reports both in KiB
     if len(vals) != 2:
         return {"traffic": None}
-    return {"traffic": vals["FETCH_SIZE"] + vals["WRITE_SIZE"],
-            "traffic_note": f"bytes per launch, {os.path.basename(files[-1])}: FETCH_SIZE {vals['FETCH_SIZE']:.3g} B (dword-per-lane "
-                            "reads, taken at face value: the guide's x2 gfx950 correction is calibrated for 16-B/lane streaming "
-                            f"reads only) + WRITE_SIZE {vals['WRITE_SIZE']:.3g} B (state write-back plus the write-back of "
-                            "register-spill scratch)"}
+    # gfx950: FETCH_SIZE tallies 128-B requests at 64 B (MI355X_MICROARCH.md, HBM / rocprofv3 section): doubled, as the guide
+    # prescribes, before it is compared with a byte count (an upper bound here: the guide calibrates the factor on 16-B-per-lane
+    # streaming reads, this kernel reads a dword per lane); WRITE_SIZE is exact
+    return {"traffic": 2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"],
+            "traffic_note": f"bytes per launch, {os.path.basename(files[-1])}: 2 x FETCH_SIZE {vals['FETCH_SIZE']:.3g} B (gfx950 correction of "
+                            f"the guide; face value would be the lower bound) + WRITE_SIZE {vals['WRITE_SIZE']:.3g} B (state, observation stack "
+                            "and info write-back, plus register-spill scratch in the kernels that spill)"}
 
 
 def free_port():
