@@ -255,7 +255,11 @@ struct CtLds {
   // origin, prisms per strip row, lowest point of the geom
   int hf_end[HF ? 24 : 1], hf_cnt[HF ? 24 : 1], hf_cmin[HF ? 24 : 1], hf_rmin[HF ? 24 : 1], hf_ppr[HF ? 24 : 1];
   int hf_list[HF ? 128 : 1];   // work items the probe pass could not decide, in order, waiting for a full batch
-  int hf_zlist[HF ? 128 : 1];  // work items that passed the height test, in order, waiting for a full probe batch
+  // work items that passed the height test, in order, waiting for a full probe batch: < 64 left over + one height pass of HFB x 64
+  // (three sub-batches where hundreds of contact slots say "fine terrain under a big robot", two elsewhere: 256 more bytes would cost
+  // the flamingo_light_v1 heightfield kernel its ninth wave per CU)
+  static constexpr int HFB = MC >= 256 ? 3 : 2;
+  int hf_zlist[HF ? 64 + 64 * HFB : 1];
   float hf_mg[HF ? 24 : 1];    // per geom: contact margin
   float hf_lo[HF ? 24 : 1];
 };
@@ -1247,12 +1251,15 @@ __global__ __launch_bounds__(64, (EPW == 2 ? 2 : (163840 / (int)sizeof(typename 
                     maybe = mpr_probe(sup, c1, o.center);
                   }
                 }
-                const int moved = (ln + 64 < nz) ? S.hf_zlist[ln + 64] : 0;
+                int moved[L::HFB];
+#pragma unroll
+                for (int j = 0; j < L::HFB; j++) moved[j] = (ln + 64 * (j + 1) < nz) ? S.hf_zlist[ln + 64 * (j + 1)] : 0;
                 const unsigned long long mm_ = __ballot(maybe);
                 if (maybe) S.hf_list[nlist + __popcll(mm_ & lanemask_lt(ln))] = item;
                 nlist += __popcll(mm_);
                 WSYNC();
-                if (ln + 64 < nz) S.hf_zlist[ln] = moved;
+#pragma unroll
+                for (int j = 0; j < L::HFB; j++) if (ln + 64 * (j + 1) < nz) S.hf_zlist[ln + 64 * j] = moved[j];
                 nz -= cnt;
                 WSYNC();
                 PEXT_ADD(1);
@@ -1263,26 +1270,51 @@ __global__ __launch_bounds__(64, (EPW == 2 ? 2 : (163840 / (int)sizeof(typename 
                 if (__builtin_amdgcn_readfirstlane(S.hf_cnt[g0]) >= 50) {   // this geom has its 50 contacts: skip the rest of its prisms
                   base = __builtin_amdgcn_readfirstlane(S.hf_end[g0]);
                 } else {
-                  const int item = base + ln;
-                  bool alive = false;
-                  if (item < total) {
-                    int g = g0;
-                    while (item >= S.hf_end[g]) g++;
-                    const int k = item - (g > 0 ? S.hf_end[g > 0 ? g - 1 : 0] : 0), ppr = S.hf_ppr[g], rrow = k / ppr, kk = k - rrow * ppr;
-                    const int r = S.hf_rmin[g] + rrow, cmin = S.hf_cmin[g];
-                    const float lo2 = S.hf_lo[g], add = T.gz + S.hf_mg[g];
+                  // HB sub-batches of 64 items per pass, their height loads in flight together (one dependent trip per 64 items
+                  // made this pass a chain of memory latencies: 217 trips per substep for a fallen humanoid on 1 cm cells)
+                  constexpr int HB = L::HFB;
+                  bool alive[HB];
+                  float hv[HB][3], lo2[HB], add[HB];
+#pragma unroll
+                  for (int j = 0; j < HB; j++) {
+                    const int item = base + ln + 64 * j;
+                    alive[j] = false;
+                    lo2[j] = 0.f; add[j] = 0.f;
+                    int idx[3] = {0, 0, 0};
+                    if (item < total) {
+                      int g = g0;
+                      while (item >= S.hf_end[g]) g++;
+                      const int k = item - (g > 0 ? S.hf_end[g > 0 ? g - 1 : 0] : 0), ppr = S.hf_ppr[g], rrow = k / ppr, kk = k - rrow * ppr;
+                      const int r = S.hf_rmin[g] + rrow, cmin = S.hf_cmin[g];
+                      lo2[j] = S.hf_lo[g]; add[j] = T.gz + S.hf_mg[g];
+#pragma unroll
+                      for (int i = 0; i < 3; i++) {
+                        const int v = kk + i, c = cmin + (v >> 1), rr = r + 1 - (v & 1);
+                        idx[i] = rr * T.ncol + c;
+                      }
+                      alive[j] = S.hf_cnt[g] < 50;
+                    }
+                    // (a sub-batch past the end of the list is skipped by the whole wave: short walks pay for one)
+                    if (j == 0 || __builtin_amdgcn_readfirstlane(base) + 64 * j < __builtin_amdgcn_readfirstlane(total)) {
+#pragma unroll
+                      for (int i = 0; i < 3; i++) hv[j][i] = T.data[idx[i]];
+                    } else {
+#pragma unroll
+                      for (int i = 0; i < 3; i++) hv[j][i] = 0.f;
+                    }
+                  }
+#pragma unroll
+                  for (int j = 0; j < HB; j++) {
+                    if (j > 0 && !(__builtin_amdgcn_readfirstlane(base) + 64 * j < __builtin_amdgcn_readfirstlane(total))) break;
                     bool below = true;
 #pragma unroll
-                    for (int i = 0; i < 3; i++) {
-                      const int v = kk + i, c = cmin + (v >> 1), rr = r + 1 - (v & 1);
-                      below = below && (T.data[rr * T.ncol + c] * T.sz + add < lo2);
-                    }
-                    alive = !below && S.hf_cnt[g] < 50;
+                    for (int i = 0; i < 3; i++) below = below && (hv[j][i] * T.sz + add[j] < lo2[j]);
+                    const bool al = alive[j] && !below;
+                    const unsigned long long am = __ballot(al);
+                    if (al) S.hf_zlist[nz + __popcll(am & lanemask_lt(ln))] = base + ln + 64 * j;
+                    nz += __popcll(am);
                   }
-                  const unsigned long long am = __ballot(alive);
-                  if (alive) S.hf_zlist[nz + __popcll(am & lanemask_lt(ln))] = item;
-                  nz += __popcll(am);
-                  base += 64;
+                  base += 64 * HB;
                   WSYNC();
                 }
                 walked = base >= total;
