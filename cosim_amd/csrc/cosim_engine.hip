@@ -448,11 +448,13 @@ int cosim_create(const cosim_model_t* model, const float* hull_vert, const int* 
     if (!hf) e->launch_prof = launch_prof_t<14, 10, 2, false, G_MESH, true, 32>;
   }
   else if (nv == 22 && nb <= 18 && (gtm & ~G_MESH) == 0) {   // w4_p_v2
-    select_t<22, 18, 2, G_MESH, true, 128, 128>(e, hf);
+    // plane: at most 4 contacts per geom (17 geoms); 80 slots keep the env at 19 KB of LDS = the 8 waves per CU its 256 registers allow
+    select_t<22, 18, 2, G_MESH, true, 80, 128>(e, hf);
     if (hf) e->launch_prof = launch_prof_t<22, 18, 2, true, G_MESH, true, 128>;
   }
   else if (nv == 29 && nb <= 26 && (gtm & ~G_HUM) == 0) {     // humanoid_p_v0
-    select_t<29, 26, 2, G_HUM, true, 128, 256>(e, hf);
+    // plane: at most 4 contacts per geom (22 geoms); 96 slots = 6 waves per CU instead of 5
+    select_t<29, 26, 2, G_HUM, true, 96, 256>(e, hf);
     if (hf) e->launch_prof = launch_prof_t<29, 26, 2, true, G_HUM, true, 256>;
   }
   else { delete e; return fail(COSIM_EINVAL, "cosim_create: no kernel instantiation for this (nv, nbody); add one in cosim_engine.hip"); }
