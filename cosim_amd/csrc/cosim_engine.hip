@@ -85,12 +85,20 @@ template <int NV, int NB, int GTM>
 static void launch_prof2_t(cosim_engine* e, const KArgs& a, int grid, hipStream_t s) {
   hipLaunchKernelGGL((env_kernel<NV, NB, 2, false, GTM, false, true, 2>), dim3((grid + 1) / 2), dim3(64), 0, s, a);
 }
-// MCT_FLAT / MCT_HF: ground-contact slots of the contact-twist kernels on a plane / on a heightfield (0: dense contact rows)
-template <int NV, int NB, int RPL, int GTM, bool SC, int MCT_FLAT, int MCT_HF>
-static void select_t(cosim_engine* e, bool hf) {
-  e->launch = hf ? launch_t<NV, NB, RPL, true, GTM, SC, MCT_HF> : launch_t<NV, NB, RPL, false, GTM, SC, MCT_FLAT>;
+// MCT_FLAT / MCT_HF / MCT_HFC: ground-contact slots of the contact-twist kernels on a plane / on a heightfield / on a COARSE
+// heightfield (cells of 10 cm or more: the reference's rocky_* and slope_* fields have 55 cm cells, a geom lies over a handful of
+// prisms, and the slots that stairs with 1 cm cells need would only cost resident waves; 0: dense contact rows)
+template <int NV, int NB, int RPL, int GTM, bool SC, int MCT_FLAT, int MCT_HF, int MCT_HFC = MCT_HF>
+static void select_t(cosim_engine* e, bool hf, bool coarse = false) {
   using LH = typename KTraits<NV, NB, RPL, true, SC, 1, MCT_HF>::L;
+  using LC = typename KTraits<NV, NB, RPL, true, SC, 1, MCT_HFC>::L;
   using LF = typename KTraits<NV, NB, RPL, false, SC, 1, MCT_FLAT>::L;
+  if (hf && coarse && MCT_HFC != MCT_HF) {
+    e->launch = launch_t<NV, NB, RPL, true, GTM, SC, MCT_HFC>;
+    e->lds_bytes = (int)sizeof(LC); e->contact_slots = LC::MC; e->pair_slots = LC::MCP; e->geom_stage = 64;
+    return;
+  }
+  e->launch = hf ? launch_t<NV, NB, RPL, true, GTM, SC, MCT_HF> : launch_t<NV, NB, RPL, false, GTM, SC, MCT_FLAT>;
   e->lds_bytes = hf ? (int)sizeof(LH) : (int)sizeof(LF);
   e->contact_slots = hf ? LH::MC : LF::MC;
   e->pair_slots = hf ? LH::MCP : LF::MCP;
@@ -418,6 +426,9 @@ int cosim_create(const cosim_model_t* model, const float* hull_vert, const int* 
   const int nv = model->nv, nb = model->nbody;
   // kernel instantiations: (nv, nbody) of the four cosim robots; RPL = constraint rows per lane
   const bool hf = model->ground_type == CS_GEOM_HFIELD;
+  // coarse field: both cell edges at least 10 cm (see select_t)
+  const bool coarse = hf && model->hfield_ncol > 1 && model->hfield_nrow > 1 && 2.0 * model->hfield_size[0] / (model->hfield_ncol - 1) >= 0.1 &&
+                      2.0 * model->hfield_size[1] / (model->hfield_nrow - 1) >= 0.1;
   int gtm = 0;   // geom types present: the kernel is specialised on them (bit 0 sphere, 1 cylinder, 2 box, 3 mesh)
   std::vector<char> in_pair(model->ngeom > 0 ? model->ngeom : 1, 0);
   for (int p = 0; p < model->npair; p++) { in_pair[model->pair_geom1[p]] = 1; in_pair[model->pair_geom2[p]] = 1; }
@@ -433,7 +444,7 @@ int cosim_create(const cosim_model_t* model, const float* hull_vert, const int* 
   }
   constexpr int G_LIGHT = GT_SPHERE | GT_CYLINDER | GT_MESH, G_MESH = GT_MESH, G_HUM = GT_BOX | GT_CYLINDER | GT_MESH;
   if (nv == 18 && nb <= 14 && (gtm & ~G_LIGHT) == 0) {   // flamingo_light_v1
-    select_t<18, 14, 1, G_LIGHT, false, 0, 128>(e, hf);
+    select_t<18, 14, 1, G_LIGHT, false, 0, 128, 48>(e, hf, coarse);
     if (!hf) {
       e->launch_prof = launch_prof_t<18, 14, 1, false, G_LIGHT, false, 0>; e->launch2 = launch2_t<18, 14, G_LIGHT>; e->launch_prof2 = launch_prof2_t<18, 14, G_LIGHT>;
       // the same robot on the plane with its ground contacts in twist space (32 slots instead of 12; cosim_set_param "contact_twist")
@@ -444,12 +455,12 @@ int cosim_create(const cosim_model_t* model, const float* hull_vert, const int* 
     }
   }
   else if (nv == 14 && nb <= 10 && (gtm & ~G_MESH) == 0) {   // flamingo_p_v3
-    select_t<14, 10, 2, G_MESH, true, 32, 64>(e, hf);
+    select_t<14, 10, 2, G_MESH, true, 32, 64, 48>(e, hf, coarse);
     if (!hf) e->launch_prof = launch_prof_t<14, 10, 2, false, G_MESH, true, 32>;
   }
   else if (nv == 22 && nb <= 18 && (gtm & ~G_MESH) == 0) {   // w4_p_v2
     // plane: at most 4 contacts per geom (17 geoms); 80 slots keep the env at 19 KB of LDS = the 8 waves per CU its 256 registers allow
-    select_t<22, 18, 2, G_MESH, true, 80, 128>(e, hf);
+    select_t<22, 18, 2, G_MESH, true, 80, 128, 48>(e, hf, coarse);
     if (hf) e->launch_prof = launch_prof_t<22, 18, 2, true, G_MESH, true, 128>;
   }
   else if (nv == 29 && nb <= 26 && (gtm & ~G_HUM) == 0) {     // humanoid_p_v0

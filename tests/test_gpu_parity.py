@@ -348,7 +348,8 @@ def test_other_robots_one_control_step_replay_flat(env_id, steps):
 
 
 @pytest.mark.parametrize("env_id,terrain,hm", [("flamingo_light_v1", "rocky_hard", False), ("w4_p_v2", "rocky_hard", True),
-                                                ("flamingo_light_v1", "slope_hard", False), ("humanoid_p_v0", "rocky_hard", False)])
+                                                ("flamingo_light_v1", "slope_hard", False), ("humanoid_p_v0", "rocky_hard", False),
+                                                ("flamingo_light_v1", "stairs_up_easy", False)])   # 1 cm cells: the fine-terrain variant
 def test_heightfield_terrain_replay_and_height_map(env_id, terrain, hm):
     """Heightfield ground (config 3: w4_p_v2 on rocky_hard): robots dropped at scattered places of the terrain; prism-MPR
     contacts (mjc_ConvexHField) and one-step replay against the oracle, and the height-map observation against the
@@ -362,8 +363,9 @@ def test_heightfield_terrain_replay_and_height_map(env_id, terrain, hm):
     cfg = make_config(env_id, terrain=terrain, random=PARITY_RANDOM, height_map=hm)
     cm = compile_model(cfg)
     b = cm.blob
-    assert b.ground_type == 1 and cm.hfield.shape == (512, 512)
-    half = 0.7 * b.hfield_size[0]                                      # scatter over most of the field (64 m or 140 m half-extent)
+    stairs = terrain.startswith("stairs")
+    assert b.ground_type == 1 and cm.hfield.shape == ((1024, 1024) if stairs else (512, 512))
+    half = 0.7 * b.hfield_size[0]                                      # scatter over most of the field (140 m half-extent; stairs: 5 m)
     rng = np.random.default_rng(11)
     o = Oracle(cm)
     q0 = np.array(get_field(b, "init_qpos")[:b.nq])
@@ -383,7 +385,7 @@ def test_heightfield_terrain_replay_and_height_map(env_id, terrain, hm):
             R["tilt"].append(float(np.abs(o.contacts()[:, 4:6]).max()) if o.ncon else 0.0)
     R = {k: np.array(v) for k, v in R.items()}
     n = len(R["qpos"])
-    assert R["ncon"].max() >= 4 and R["tilt"].max() > 0.02            # the samples really sit on sloped triangles
+    assert R["ncon"].max() >= 4 and (stairs or R["tilt"].max() > 0.02)   # the samples really sit on sloped triangles (stairs: on 1 cm cells)
     env = BatchedEnv(cfg, num_envs=n, auto_reset=False, compiled=cm)
     env.reset()
     env.set_state(R["qpos"], R["qvel"], R["warm"])
@@ -391,9 +393,19 @@ def test_heightfield_terrain_replay_and_height_map(env_id, terrain, hm):
     d = env.get_data()
     qp, qv = d.qpos.cpu().numpy().astype(np.float64), d.qvel.cpu().numpy().astype(np.float64)
     st = env.solver_stats()
-    assert st["dropped_contacts"] == 0 and st["max_contacts"] >= R["ncon"].max() - 2     # no capacity mask: every state is compared
     ep = np.abs(qp - R["qpos1"]).max(axis=1)
     ev = np.abs(qv - R["qvel1"]).max(axis=1)
+    slots = int(env.engine.query("contact_slots"))
+    if stairs:
+        # a fallen robot on 1 cm cells collects up to 50 contacts per geom (230 here): more than this robot's 128 slots in a few states.
+        # What does not fit must be COUNTED, and every state that fits is compared
+        assert slots == 128 and R["ncon"].max() > slots and st["dropped_contacts"] > 0 and st["max_contacts"] >= R["ncon"].max() - 8
+        fits = R["ncon"] <= slots - 16
+        assert fits.sum() >= 0.9 * n
+        ep, ev = ep[fits], ev[fits]
+    else:
+        assert slots == (256 if env_id == "humanoid_p_v0" else 48)                          # coarse-terrain variants (55 cm cells)
+        assert st["dropped_contacts"] == 0 and st["max_contacts"] >= R["ncon"].max() - 2     # no capacity mask: every state is compared
     # MPR on a prism ridge is ill-conditioned (the portal lands on either neighbouring face): a few percent of the contacts
     # get the other face's normal under fp32 poses, so the replay is judged on quantiles, the contact sets below exactly
     assert np.median(ep) < 2e-5 and np.quantile(ep, 0.9) < 2e-4, (np.median(ep), np.quantile(ep, 0.9), ep.max())
@@ -401,7 +413,7 @@ def test_heightfield_terrain_replay_and_height_map(env_id, terrain, hm):
     # --- narrowphase parity (mjc_ConvexHField restatement): same prisms hit, same depth / position / normal
     env.set_state(R["qpos"], R["qvel"], R["warm"])
     same_set = tight = total = 0
-    sample = range(0, n, 3)
+    sample = [w for w in range(0, n, 3) if R["ncon"][w] <= slots - 16]
     for w in sample:
         o.reset(R["qpos"][w], R["qvel"][w])
         o.forward()
