@@ -461,7 +461,7 @@ int cosim_create(const cosim_model_t* model, const float* hull_vert, const int* 
   else if (nv == 22 && nb <= 18 && (gtm & ~G_MESH) == 0) {   // w4_p_v2
     // plane: at most 4 contacts per geom (17 geoms); 80 slots keep the env at 19 KB of LDS = the 8 waves per CU its 256 registers allow
     select_t<22, 18, 2, G_MESH, true, 80, 128, 48>(e, hf, coarse);
-    if (hf) e->launch_prof = launch_prof_t<22, 18, 2, true, G_MESH, true, 128>;
+    if (hf && coarse) e->launch_prof = launch_prof_t<22, 18, 2, true, G_MESH, true, 48>;   // diagnostic build of the config-3 kernel
   }
   else if (nv == 29 && nb <= 26 && (gtm & ~G_HUM) == 0) {     // humanoid_p_v0
     // plane: at most 4 contacts per geom (22 geoms); 96 slots = 6 waves per CU instead of 5
