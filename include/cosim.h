@@ -84,7 +84,12 @@ int cosim_query(const cosim_engine_t* e, const char* name);
  * even env counts), "wave_priority" (count 4: s_setprio by solver lag -- Newton iterations taken as usual per substep, then the
  * lag thresholds of priority 1, 2, 3; a huge first threshold switches it off), "debug_substeps" (diagnostics: physics substeps
  * per control step, 0 = frame_skip), "boxbox_mode" (1, default: box-box geom pairs through the mjc_BoxBox routine, up to eight contacts
- * per pair; 0: through MPR like the other convex pairs, one contact). */
+ * per pair; 0: through MPR like the other convex pairs, one contact), "pair_mode" (1, default: robot-robot pairs with a hull one at
+ * a time with wave-cooperative vertex scans; 0: lane-parallel), "contact_twist" (flat flamingo_light_v1 only; 1: ground contacts in
+ * twist space, 32 slots instead of the dense-row kernel's 12, at ~70 % of the speed; before the first step), "ls_tolerance_scale"
+ * (multiplies the line-search tolerance; 1 = the model's).
+ * cosim_query additionally answers "contact_slots" / "pair_slots" (capacity of the selected kernel variant: heightfields with cells
+ * of 10 cm or more select the 48-slot variants of flamingo_* / w4_p_v2) and "lds_bytes". */
 int cosim_set_param(cosim_engine_t* e, const char* name, const float* host, int count);
 
 /* Replaces env.reset() (reference envs/wrappers.py:245-256,303-307,385-389; flamingo_light_v1.py:209-232).
