@@ -589,7 +589,9 @@ __global__ __launch_bounds__(64, (EPW == 2 ? 2 : (163840 / (int)sizeof(typename 
   if (env >= A.n_envs) return;
   typedef const DevModel __attribute__((address_space(4)))* DevModelP;   // the model never changes while a kernel runs: constant address space = invariant loads
   const auto& dm = *(DevModelP)(unsigned long long)A.dm;
-#define ob (*A.ob)
+  typedef const DevObs __attribute__((address_space(4)))* DevObsP;   // wrapper configuration: constant for the engine's lifetime
+  const DevObsP ob_p = (DevObsP)(unsigned long long)A.ob;
+#define ob (*ob_p)
 #define lay (A.lay)
   float* rec = A.state + (size_t)env * lay.s_stride;
   const float* par = A.params + (size_t)env * lay.p_stride;
@@ -2471,6 +2473,17 @@ __global__ __launch_bounds__(64, (EPW == 2 ? 2 : (163840 / (int)sizeof(typename 
     const int sd = ob.stacked_dim, S_ = ob.stack_size;
     for (int e = lane; e < ob.frame_dim; e += LW) {
       const int f = ob.el_field[e], idx = ob.el_index[e];
+      // the rows of the observation stack that move down and the cached element: their loads (first touch of these lines in this
+      // launch: HBM latency) are issued here, ahead of the observation arithmetic, not one dependent trip per stack row after it
+      float* const cache = rec + lay.s_cache + e;
+      float* const st = rec + lay.s_stack;
+      const float cached = *cache;
+      float old[4] = {0.f, 0.f, 0.f, 0.f};
+      const bool short_stack = S_ <= 5;
+      if (e < sd && !fill && short_stack) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) if (k < S_ - 1) old[k] = st[k * sd + e];
+      }
       float val = 0.f;
       switch (f) {
         case CS_OBS_DOF_POS: val = S.qpos[dm.rec[idx].o_qadr] * dm.rec[idx].o_qgear; break;
@@ -2511,18 +2524,26 @@ __global__ __launch_bounds__(64, (EPW == 2 ? 2 : (163840 / (int)sizeof(typename 
       }
       float vs;
       const int interval = ob.el_interval[e];
-      float* cache = rec + lay.s_cache + e;
       if (f == CS_OBS_COMMAND) vs = 0.f;
       else if (sim_step == 0 || (sim_step % interval) == 0) { vs = val * ob.el_scale[e]; *cache = vs; }
-      else vs = *cache;
+      else vs = cached;
       const bool is_cmd = f == CS_OBS_COMMAND;
       const float cmdv = is_cmd ? S.cmd[idx] : 0.f;
       if (e < sd) {
-        float* st = rec + lay.s_stack;
-        for (int k = S_ - 1; k >= 1; k--) {
-          float o = fill ? vs : st[(k - 1) * sd + e];
-          st[k * sd + e] = o;
-          so[k * sd + e] = is_cmd ? cmdv : o;
+        if (short_stack) {
+#pragma unroll
+          for (int k = 4; k >= 1; k--)
+            if (k < S_) {
+              const float o = fill ? vs : old[k - 1];
+              st[k * sd + e] = o;
+              so[k * sd + e] = is_cmd ? cmdv : o;
+            }
+        } else {
+          for (int k = S_ - 1; k >= 1; k--) {
+            float o = fill ? vs : st[(k - 1) * sd + e];
+            st[k * sd + e] = o;
+            so[k * sd + e] = is_cmd ? cmdv : o;
+          }
         }
         st[e] = vs;
         so[e] = is_cmd ? cmdv : vs;
