@@ -919,6 +919,41 @@ def test_full_size_fleet_is_sharding_and_size_invariant():
     fleet.close(); shard.close()
 
 
+@pytest.mark.parametrize("env_id,terrain,n,hm,poscmd,steps", [("w4_p_v2", "rocky_hard", 4096, True, False, 40),
+                                                             ("flamingo_p_v3", "flat", 4096, False, False, 40),
+                                                             ("humanoid_p_v0", "stairs_up_hard", 1024, False, True, 12)])
+def test_full_size_fleets_of_the_other_configs_are_sharding_invariant(env_id, terrain, n, hm, poscmd, steps):
+    """BASELINE configs 3, 4 and 5 at their per-GPU sizes (bench.py's workloads: GUI-default randomisation, sensor noise, sinusoid
+    drive, auto-reset): a 64-env shard placed inside the id range reproduces the fleet's rows bit for bit, the fleet stays finite, the
+    envs differ and the contact capacity is not exceeded (config 5: what exceeds it is counted)."""
+    import torch
+    from bench import synthetic_actions
+    from cosim_amd.batched_env import BatchedEnv
+    from cosim_amd.compile import compile_model
+    from cosim_amd.config import make_config
+    cfg = make_config(env_id, terrain=terrain, num_envs=n, seed=1234, height_map=hm, position_command=poscmd)
+    if poscmd:
+        cfg["observation"]["command_dim"] = 2
+    cm = compile_model(cfg)
+    fleet = BatchedEnv(cfg, num_envs=n, seed=1234, auto_reset=True, gain_noise=0.1, compiled=cm)
+    lo = (n * 5) // 7
+    shard = BatchedEnv(cfg, num_envs=64, seed=1234, auto_reset=True, gain_noise=0.1, env_id0=lo, compiled=cm)
+    acts = synthetic_actions(n, 0, steps, fleet.action_dim, fleet.device)
+    cmd = np.array([0.5, 0.0, 0.0, 0.0], dtype=np.float32)[:max(fleet.command_dim, 1)]
+    fleet.receive_user_command(cmd); shard.receive_user_command(cmd)
+    sf, _ = fleet.reset(); ss, _ = shard.reset()
+    assert torch.equal(sf[lo:lo + 64], ss)
+    for t in range(steps):
+        sf, tf, cf, _ = fleet.step(acts[t]); ss, ts, cs, _ = shard.step(acts[t, lo:lo + 64].contiguous())
+    assert torch.equal(sf[lo:lo + 64], ss) and torch.equal(fleet.get_data().qpos[lo:lo + 64], shard.get_data().qpos)
+    st = fleet.solver_stats()
+    assert bool(torch.isfinite(sf).all()) and st["nan_resets"] == 0
+    assert float(sf.std(dim=0).max()) > 1e-3 and st["newton_iters"] > n * steps * 4
+    if env_id != "humanoid_p_v0":
+        assert st["dropped_contacts"] == 0 and st["max_contacts"] <= int(fleet.engine.query("contact_slots"))
+    fleet.close(); shard.close()
+
+
 def test_two_envs_per_wave_variant_agrees_with_the_default_kernel(parity):
     """The opt-in kernel variant (two 32-lane groups per wave, mfma_32x32x1_2b Hessians) against the default one: one
     control step from 256 states along a driven trajectory; different summation orders, same physics."""
