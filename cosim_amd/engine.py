@@ -42,6 +42,13 @@ class ObsConfig(ctypes.Structure):
     ]
 
 
+# Packed fp32 (v_pk_fma_f32) pays in the solver's long FMA chains, but the SLP vectoriser's default cost model also packs the
+# quaternion / cross-product code, where the v_mov shuffles around each packed op cost more than the op saves (kinematics: 243
+# moves for 237 packed ops).  Measured on MI355X, 1000-step benches, threshold 0 (default) / 1 / 2 / 3 / 4 / off: headline
+# 13.00 / 13.17 / 13.23 / 13.36 / 11.87 / 11.5 M env-steps/s, p_v3_flat 7.9 / 8.3 / 8.8 / 8.3 / 7.4, w4_rocky 2.73 / 2.76 / 2.86 / 2.87 / 2.85.
+HIPCC_TUNING = ["-mllvm", "-slp-threshold=2"]
+
+
 def build_library(force: bool = False, verbose: bool = False) -> str:
     """Compile the HIP engine for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
     # every file the translation unit pulls in (cosim_engine.hip includes the other .hip / .h files of csrc/)
@@ -53,7 +60,7 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
         if os.path.getmtime(LIB_PATH) >= newest:
             return LIB_PATH
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value",
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value", *HIPCC_TUNING,
            "-o", LIB_PATH, os.path.join(CSRC, "cosim_engine.hip")]
     if verbose:
         cmd.append("-Rpass-analysis=kernel-resource-usage")

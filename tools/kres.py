@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Rebuild libcosim_hip.so with -Rpass-analysis=kernel-resource-usage and print one line per kernel.
 
-    python tools/kres.py            # table: kernel, VGPRs, AGPRs, SGPR/VGPR spills, scratch B/lane, occupancy, LDS
+    python tools/kres.py [flags]    # table: kernel, VGPRs, AGPRs, SGPR/VGPR spills, scratch B/lane, occupancy, LDS
+                                    # (extra hipcc flags replace the product build's tuning flags, engine.HIPCC_TUNING)
 """
 import os
 import re
@@ -13,10 +14,10 @@ sys.path.insert(0, ROOT)
 
 
 def main():
-    from cosim_amd.engine import CSRC, LIB_PATH
+    from cosim_amd.engine import CSRC, HIPCC_TUNING, LIB_PATH
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value", "-o", LIB_PATH,
-           os.path.join(CSRC, "cosim_engine.hip"), "-Rpass-analysis=kernel-resource-usage"] + sys.argv[1:]
+           os.path.join(CSRC, "cosim_engine.hip"), "-Rpass-analysis=kernel-resource-usage"] + (sys.argv[1:] if len(sys.argv) > 1 else HIPCC_TUNING)
     p = subprocess.run(cmd, capture_output=True, text=True)
     if p.returncode:
         sys.stderr.write(p.stderr)
