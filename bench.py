@@ -276,13 +276,8 @@ def main(argv=None):
         for i in range(S):
             with torch.cuda.stream(streams[i]):
                 env.step_range(i * ns, ns, a)
-        if report:   # reporter statistics of this step: the reducer reads every range's info rows, the ranges' next launches wait for it
-            for i in range(S):
-                streams[0].wait_stream(streams[i])
-            with torch.cuda.stream(streams[0]):
-                reporter.write_info(None)
-            for i in range(1, S):
-                streams[i].wait_stream(streams[0])
+                if report:   # reporter statistics of this step: each range's info rows are reduced on that range's own stream
+                    reporter.write_info_range(i * ns, ns)
 
     for st_ in streams:
         st_.wait_stream(main)

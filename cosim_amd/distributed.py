@@ -63,7 +63,8 @@ class MetricsAccumulator:
         if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
             # fp64 is fine for gloo; RCCL reduces fp64 as well
             dist.all_reduce(buf, op=dist.ReduceOp.SUM)
-        n = buf[0].clamp(min=1)
-        mean = buf[1] / n
-        var = (buf[2] / n - mean * mean).clamp(min=0)
-        return {k: {"count": float(buf[0, i]), "mean": float(mean[i]), "std": float(var[i].sqrt())} for i, k in enumerate(self.names)}
+        b = buf.cpu().numpy()                      # ONE device-to-host copy; the per-metric arithmetic runs on the host
+        n = np.maximum(b[0], 1.0)
+        mean = b[1] / n
+        std = np.sqrt(np.maximum(b[2] / n - mean * mean, 0.0))
+        return {k: {"count": float(b[0, i]), "mean": float(mean[i]), "std": float(std[i])} for i, k in enumerate(self.names)}

@@ -37,6 +37,26 @@ class FleetReporter:
         self.steps = 0
         self.episodes_ended = 0
 
+    def write_info_range(self, first: int, count: int):
+        """GPU fast path for a fleet stepped as several ranges on streams of their own (``BatchedEnv.step_range``): reduce the info
+        rows of envs [first, first + count) on the CURRENT stream -- the stream that range's step was launched on -- into the shared
+        accumulator (double atomics), so sampling a step needs no cross-stream wait.  Call once per range; ``steps`` counts one
+        sampled step when the last range (first + count == num_envs) is written."""
+        if not (self._fast and self._lib is not None):
+            raise RuntimeError("write_info_range needs the BatchedEnv GPU path (libcosim_hip.so)")
+        t = self.env.torch
+        e = self.env
+        nu, cd = e.action_dim, min(e.command_dim, 3)
+        if first < 0 or count <= 0 or first + count > e.num_envs:
+            raise ValueError("write_info_range: range outside the fleet")
+        rc = self._lib.cosim_fleet_stats(e.info_buf.data_ptr() + first * e.info_buf.shape[1] * 4, count, e.info_buf.shape[1], nu,
+                                         e.user_command.data_ptr() + first * e.user_command.shape[1] * 4, e.user_command.shape[1], cd,
+                                         self.acc.buf.data_ptr(), t.cuda.current_stream(e.device).cuda_stream)
+        if rc != 0:
+            raise RuntimeError(self._lib.cosim_last_error().decode())
+        if first + count == e.num_envs:
+            self.steps += 1
+
     def write_info(self, info):
         """``info``: the dict of ``BatchedEnv.step`` (on the GPU fast path it is only a token: the statistics are reduced from
         the env's own ``info_buf`` / ``user_command`` buffers, which the dict's entries are views of)."""

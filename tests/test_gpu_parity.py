@@ -1014,7 +1014,7 @@ def test_fused_fleet_statistics_match_the_tensor_path():
     from cosim_amd.config import make_config
     from cosim_amd.reporter import FleetReporter
     env = BatchedEnv(make_config("flamingo_light_v1", num_envs=300, seed=2), num_envs=300, seed=2, auto_reset=True)
-    fast, slow = FleetReporter(env), FleetReporter(env)
+    fast, slow, ranged = FleetReporter(env), FleetReporter(env), FleetReporter(env)
     assert fast._lib is not None
     slow._lib = None                                                  # forces the tensor path
     env.reset()
@@ -1023,8 +1023,12 @@ def test_fused_fleet_statistics_match_the_tensor_path():
     for t in range(25):
         _, _, _, info = env.step(0.3 * torch.randn((300, 4), device=env.device, generator=g))
         fast.write_info(info); slow.write_info(info)
-    a, b = fast.summary()["metrics"], slow.summary()["metrics"]
-    assert set(a) == set(b) and a["lin_vel_x"]["count"] == 300 * 25
+        ranged.write_info_range(0, 172); ranged.write_info_range(172, 128)      # the bench's per-range sampling (two uneven ranges)
+    a, b, c = fast.summary()["metrics"], slow.summary()["metrics"], ranged.summary()["metrics"]
+    assert set(a) == set(b) == set(c) and a["lin_vel_x"]["count"] == 300 * 25 == c["lin_vel_x"]["count"] and ranged.steps == 25
     for k in a:
         assert a[k]["mean"] == pytest.approx(b[k]["mean"], rel=1e-5, abs=1e-7) and a[k]["std"] == pytest.approx(b[k]["std"], rel=1e-4, abs=1e-6), k
+        assert c[k]["mean"] == pytest.approx(a[k]["mean"], rel=1e-6, abs=1e-8) and c[k]["std"] == pytest.approx(a[k]["std"], rel=1e-5, abs=1e-7), k
+    with pytest.raises(ValueError):
+        ranged.write_info_range(200, 128)
     env.close()
