@@ -455,8 +455,11 @@ int cosim_create(const cosim_model_t* model, const float* hull_vert, const int* 
     }
   }
   else if (nv == 14 && nb <= 10 && (gtm & ~G_MESH) == 0) {   // flamingo_p_v3
-    select_t<14, 10, 2, G_MESH, true, 32, 64, 48>(e, hf, coarse);
-    if (!hf) e->launch_prof = launch_prof_t<14, 10, 2, false, G_MESH, true, 32>;
+    // one row per lane: with the ground contacts in twist space the dense rows are the robot-robot contacts (8 slots = 32 rows), 8
+    // frictionloss rows and at most 8 limit rows (8 hinges)
+    // (no coarse-cell variant: at one row per lane the 64-slot kernel already fits the 12 waves per CU its registers allow)
+    select_t<14, 10, 1, G_MESH, true, 32, 64, 64>(e, hf, coarse);
+    if (!hf) e->launch_prof = launch_prof_t<14, 10, 1, false, G_MESH, true, 32>;
   }
   else if (nv == 22 && nb <= 18 && (gtm & ~G_MESH) == 0) {   // w4_p_v2
     // plane: at most 4 contacts per geom (17 geoms); 80 slots keep the env at 19 KB of LDS = the 8 waves per CU its 256 registers allow

@@ -1496,18 +1496,21 @@ __global__ __launch_bounds__(64, (EPW == 2 ? 2 : (163840 / (int)sizeof(typename 
             }
             // pairs with a convex hull: one at a time with all 64 lanes sharing the vertex scans (cosim_set_param "pair_mode" 0 runs them
             // lane-parallel, every lane scanning its own hulls: measured slower on the 700-vertex wheel hulls)
-            mesh = cand && A.pair_coop && (G1.g_type == CS_GEOM_MESH || G2.g_type == CS_GEOM_MESH);
+            if constexpr ((GTM & ~GT_MESH) == 0) mesh = cand;   // every geom is a hull (flamingo_p_v3, w4_p_v2): no lane-parallel route is compiled in
+            else mesh = cand && A.pair_coop && (G1.g_type == CS_GEOM_MESH || G2.g_type == CS_GEOM_MESH);
             if (PROF && !HF) { const unsigned long long sm = __ballot(d2 <= rs * rs); if (ln == 0) pext[12] += __popcll(sm); }   // pairs past the bounding spheres
             if constexpr ((GTM & GT_BOX) != 0) boxes = cand && A.pair_boxbox && G1.g_type == CS_GEOM_BOX && G2.g_type == CS_GEOM_BOX;
           }
           bool hit = false;
           float depth = 0.f, cn[3] = {0.f, 0.f, 1.f}, cp[3] = {0.f, 0.f, 0.f};
-          if (cand && !mesh && !boxes) {
-            CObj o1, o2;
-            make_cobj(o1, g1);
-            make_cobj(o2, g2);
-            const MprPair<GTM, false> sup{o1, o2, HG, ln};
-            hit = mpr_penetration(sup, o1.center, o2.center, depth, cn, cp) && (cn[0] != 0.f || cn[1] != 0.f || cn[2] != 0.f);
+          if constexpr ((GTM & ~GT_MESH) != 0) {
+            if (cand && !mesh && !boxes) {
+              CObj o1, o2;
+              make_cobj(o1, g1);
+              make_cobj(o2, g2);
+              const MprPair<GTM, false> sup{o1, o2, HG, ln};
+              hit = mpr_penetration(sup, o1.center, o2.center, depth, cn, cp) && (cn[0] != 0.f || cn[1] != 0.f || cn[2] != 0.f);
+            }
           }
           {
             const unsigned long long hm = __ballot(hit);
@@ -1727,7 +1730,7 @@ __global__ __launch_bounds__(64, (EPW == 2 ? 2 : (163840 / (int)sizeof(typename 
         G.g = S.cgeom[c] & 0xff;
         G.b = dm.rec[G.g].g_body;
         G.mu = S.p_gmu[G.g];
-        for (int k = 0; k < 3; k++) { G.n[k] = NRM ? S.cnrm[NRM ? c : 0][k] : (k == 2 ? 1.f : 0.f); G.off[k] = S.cpos[c][k] - com[k]; }
+        for (int k = 0; k < 3; k++) { G.n[k] = NRM ? S.cnrm[NRM ? c : 0][k] : (k == 2 ? 1.f : 0.f); G.off[k] = S.cpos[c][k] - S.com[k]; }   // S.com, not the register copy: that copy lives across the whole solver and was reloaded from scratch here, inside the Newton loop
         make_frame(G.n, G.t1, G.t2);
       };
       auto point_proj = [&](const float* tw, const CGeo& G, float& pn, float& p1, float& p2) {   // (n, t1, t2) . (v + w x off)
@@ -2342,7 +2345,7 @@ __global__ __launch_bounds__(64, (EPW == 2 ? 2 : (163840 / (int)sizeof(typename 
             make_frame(nrm, t1, t2);
             const float fl0 = f[0] + f[1] + f[2] + f[3], fl1 = (f[0] - f[1]) * mu, fl2 = (f[2] - f[3]) * mu;  // mj_contactForce, pyramidal
             float fw[3], dif[3], tq[3];
-            for (int k = 0; k < 3; k++) { fw[k] = nrm[k] * fl0 + t1[k] * fl1 + t2[k] * fl2; dif[k] = cp_[k] - com[k]; }
+            for (int k = 0; k < 3; k++) { fw[k] = nrm[k] * fl0 + t1[k] * fl1 + t2[k] * fl2; dif[k] = cp_[k] - S.com[k]; }
             cross(tq, dif, fw);
             const float sgn = on2 ? 1.f : -1.f;   // equal and opposite on geom1's body
             for (int k = 0; k < 3; k++) { wr[k] += sgn * tq[k]; wr[3 + k] += sgn * fw[k]; }
