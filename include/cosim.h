@@ -89,7 +89,7 @@ int cosim_query(const cosim_engine_t* e, const char* name);
  * twist space, 32 slots instead of the dense-row kernel's 12, at ~70 % of the speed; before the first step), "ls_tolerance_scale"
  * (multiplies the line-search tolerance; 1 = the model's).
  * cosim_query additionally answers "contact_slots" / "pair_slots" (capacity of the selected kernel variant: heightfields with cells
- * of 10 cm or more select the 48-slot variants of flamingo_* / w4_p_v2) and "lds_bytes". */
+ * of 10 cm or more select the 48-slot variants of flamingo_light_v1 / w4_p_v2) and "lds_bytes". */
 int cosim_set_param(cosim_engine_t* e, const char* name, const float* host, int count);
 
 /* Replaces env.reset() (reference envs/wrappers.py:245-256,303-307,385-389; flamingo_light_v1.py:209-232).
