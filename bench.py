@@ -246,10 +246,11 @@ def main(argv=None):
     n = args.envs_per_gpu or n_default
     env_id0 = rank * n
 
-    S = max(1, args.streams)
-    if n % S or (n // S) % 2:
-        raise SystemExit(f"--streams {S} must divide the envs per GPU ({n}) into even shards")
-    ns = n // S
+    S = max(1, min(args.streams, n))
+    # contiguous ranges of n // S envs, the first n % S of them one env longer
+    starts = [i * (n // S) + min(i, n % S) for i in range(S + 1)]
+    ranges = [(starts[i], starts[i + 1] - starts[i]) for i in range(S)]
+    ns = n / S                                                       # mean envs per launch (roofline.achieved is per launch)
     poscmd = args.workload == "humanoid_stairs"
     cfg = make_config(robot, terrain=terrain, num_envs=n, seed=1234, height_map=hmap, position_command=poscmd)
     if poscmd:
@@ -281,9 +282,9 @@ def main(argv=None):
         a = actions[t]
         for i in range(S):
             with torch.cuda.stream(streams[i]):
-                env.step_range(i * ns, ns, a)
+                env.step_range(ranges[i][0], ranges[i][1], a)
                 if report:   # reporter statistics of this step: each range's info rows are reduced on that range's own stream
-                    reporter.write_info_range(i * ns, ns)
+                    reporter.write_info_range(ranges[i][0], ranges[i][1])
 
     for st_ in streams:
         st_.wait_stream(main)
