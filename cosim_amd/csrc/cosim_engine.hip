@@ -49,7 +49,7 @@ struct cosim_engine {
   int nsub_override = 0;
   int pair_coop = 1;
   int pair_boxbox = 1;
-  int prio[4] = {6, -4, -2, 0};   // wave priority by solver lag (see the kernel): usual iterations per substep, lag thresholds
+  int prio[4] = {3, 0, 2, 4};   // wave priority by solver lag (see the kernel): usual iterations per substep, lag thresholds
   // timing
   bool timing = false;
   std::vector<hipEvent_t> ev;  // event pairs (start, stop) of timed launches not yet read back

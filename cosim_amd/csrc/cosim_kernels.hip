@@ -2283,7 +2283,8 @@ __global__ __launch_bounds__(64, (EPW == 2 ? 2 : (163840 / (int)sizeof(typename 
       // latency-bound phase at once.  lag = iterations so far - usual count + the wave's slot number on its SIMD
       // (HW_REG_HW_ID.WAVE_ID & 3, a tie-break).  Thresholds (cosim_set_param "wave_priority") swept on the 4096-env
       // flamingo_light_v1 bench: off 10.5 M, (3; 1, 3, 6) 10.9 M, (6; -4, -2, 0) 11.3 M, + tie-break 11.5 M, + per-iteration
-      // refresh 11.7 M env-steps/s.
+      // refresh 11.7 M env-steps/s.  Round 2, four range launches: off 13.92 M, (6; -4, -2, 0) 13.88 M, (3; 0, 2, 4) 14.07 M (the default now;
+      // every setting with base 2 ... 4 is within 0.3 % of it: with the spills and most exposed waits gone the lever is small).
       auto wave_priority = [&](int iters_so_far) {
         if constexpr (EPW == 1 && ((RPL == 1 && !HF) || NV < 18) && !PROF) {
           const int lag = iters_so_far - A.prio[0] * (sub + 1) + (int)(__builtin_amdgcn_s_getreg(4 | (0 << 6) | (3 << 11)) & 3u);
