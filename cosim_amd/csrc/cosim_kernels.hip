@@ -272,20 +272,23 @@ struct EnvLds : CtLds<(MCT > 0), HFL, NB, (MCT > 0 ? MCT : 1), (MCPT > 0 ? MCPT 
   static constexpr bool CT = MCT > 0;
   static constexpr int LD = NV | 1;   // odd leading dimension: conflict-free column access
   static constexpr int ROWS = LW * RPL;            // constraint rows per env: RPL rows per lane, LW lanes per env
-  static constexpr int MC = CT ? MCT : (ROWS <= 64 ? 12 : 16);  // contact slots (4 pyramid rows each); CT: ground contacts only
+  static constexpr int NEQR = (CT && MCPT > 0) ? 0 : 3 * MAXEQ / 2;   // rows kept for connect equalities (no cosim robot has both equalities and robot-robot pairs; a model that did would trade pair slots for them)
+  // dense rows (one per lane slot) are the connect equalities and the contacts only: friction-loss and limit rows have unit Jacobians
+  // (+-e_dof) and live in the lane of their dof ("dof rows", no slot).  64 slots = 6 equality rows + 14 contacts for flamingo_light_v1:
+  // every ground contact a fallen robot makes on the plane in the bench (most seen: 14)
+  static constexpr int MC = CT ? MCT : ((ROWS - NEQR) / 4 < 16 ? (ROWS - NEQR) / 4 : 16);  // contact slots (4 pyramid rows each); CT: ground contacts only
   static constexpr int MCP = CT ? MCPT : 1;        // CT: robot-robot contact slots (dense rows)
   static constexpr int CPL = (MC + LW - 1) / LW;   // CT: contacts per lane = passes over the contact list
-  static constexpr int NEQR = (CT && MCPT > 0) ? 0 : 3 * MAXEQ / 2;   // rows kept for connect equalities (no cosim robot has both equalities and robot-robot pairs; a model that did would trade pair slots for them)
   static constexpr int NGEN = NEQR + 4 * (CT ? MCP : MC);  // dense rows: 2 connect equalities (6 rows) + contacts
-  static constexpr int NLIM = ROWS / 8;
   static constexpr int NUMAX = NV - 6;   // actuators: at most one per hinge dof (the free joint's six dofs carry none)
-  float qpos[CS_MAXQ], qvel[NV], qacc[NV], qact[NV], qsm[NV], qcon[NV], sr[NV], dofD[NV];
-  float xpos[NB][3], xquat[NB][4], xanc[NB][3], xax[NB][3];
+  float qpos[CS_MAXQ], qvel[NV], qacc[NV], qact[NV], qsm[NV], qcon[NV], sr[NV];
+  float xpos[NB][3], xquat[NB][4];
   alignas(8) float cdof[NV][6];
   float M[NV][LD];
   union {                      // scratch that is dead before the solver starts shares the Hessian's space
     float H[NV][LD];
     struct { float cdd[NV][6], cfb[NB][6]; } v;
+    struct { float xanc[NB][3], xax[NB][3]; } k;   // joint anchors and axes: written by the kinematics sweep, dead once cdof is built
   } u;
   union {
     float cin[NB][10];         // dead after the bias forces
@@ -295,8 +298,6 @@ struct EnvLds : CtLds<(MCT > 0), HFL, NB, (MCT > 0 ? MCT : 1), (MCPT > 0 ? MCPT 
   float J[NGEN][LD];
   float cpos[MC][3], cnrm[NRM ? MC : 1][3], cdist[MC];   // contact normals are +z on the plane: not stored
   int cgeom[MC];   // geom2 | (geom1 + 1) << 8; geom1 + 1 == 0: the ground
-  int lim_body[NLIM];
-  float lim_sign[NLIM], lim_dist[NLIM];
   float p_mass[NB], p_binvw[NB], p_dinvw[NV], p_floss[NV], p_gmu[24];   // collision geoms: at most 22 (humanoid_p_v0)
   float act[NUMAX], tq[NUMAX], cmd[CS_MAXCMD + 2];
   float sens[10];   // framequat[4], gyro[3], velocimeter[3] of the last substep's forward pass
@@ -735,7 +736,7 @@ __global__ __launch_bounds__(64, (EPW == 2 ? 2 : (163840 / (int)sizeof(typename 
               }
               qnorm(xq);
             }
-            for (int k = 0; k < 3; k++) { S.xpos[b][k] = xp[k]; S.xanc[b][k] = anc[k]; S.xax[b][k] = ax[k]; }
+            for (int k = 0; k < 3; k++) { S.xpos[b][k] = xp[k]; S.u.k.xanc[b][k] = anc[k]; S.u.k.xax[b][k] = ax[k]; }
             for (int k = 0; k < 4; k++) S.xquat[b][k] = xq[k];
           }
           if (ln == 0 && lev == 1) {
@@ -819,8 +820,8 @@ __global__ __launch_bounds__(64, (EPW == 2 ? 2 : (163840 / (int)sizeof(typename 
               cross(cd + 3, axs, off);
             }
           } else {
-            float axs[3] = {S.xax[b][0], S.xax[b][1], S.xax[b][2]};
-            float off[3] = {com[0] - S.xanc[b][0], com[1] - S.xanc[b][1], com[2] - S.xanc[b][2]};
+            float axs[3] = {S.u.k.xax[b][0], S.u.k.xax[b][1], S.u.k.xax[b][2]};
+            float off[3] = {com[0] - S.u.k.xanc[b][0], com[1] - S.u.k.xanc[b][1], com[2] - S.u.k.xanc[b][2]};
             cd[0] = axs[0]; cd[1] = axs[1]; cd[2] = axs[2];
             cross(cd + 3, axs, off);
           }
@@ -1566,30 +1567,50 @@ __global__ __launch_bounds__(64, (EPW == 2 ? 2 : (163840 / (int)sizeof(typename 
       // =========================================================== constraint rows (lane = row)
       const int ne = 3 * dm.neq, nf = dm.nfric;
       int nl = 0;
-      {  // joint limits: compaction over bodies
-        const auto& R = dm.rec[ln];
+      // ---- dof rows (lane = dof): the friction-loss row and the joint-limit row of this lane's dof.  Their Jacobians are +-e_dof, so
+      // J a is a lane read of qacc, J^T f a lane add and J^T D J a diagonal add: no dense row, no lane slot, no capacity to run out of
+      // (mj_instantiateFriction / mj_instantiateLimit, engine_core_constraint.c).  fD / lD = 0: no such row on this dof.
+      float fD = 0.f, fRf = 0.f, fls = 0.f, faref = 0.f;   // friction loss: 1 / R, R f (half-width of the quadratic zone), f, aref
+      float lD = 0.f, lsg = 1.f, laref = 0.f;              // limit: 1 / R, sign of the Jacobian entry, aref
+      {
         bool lo_v = false, hi_v = false;
-        float dlo = 0.f, dhi = 0.f;
-        if (ln > 0 && ln < nbody && R.b_jtype == CS_JNT_HINGE && R.j_limited) {
-          float q = S.qpos[R.b_qadr];
-          dlo = q - R.j_range[0];
-          dhi = R.j_range[1] - q;
-          lo_v = dlo < R.j_margin;
-          hi_v = dhi < R.j_margin;
+        if (ln < NV) {
+          const auto& R = dm.rec[ln];
+          const float dinvw = S.p_dinvw[ln], vel = S.qvel[ln];
+          const float fl = S.p_floss[ln];
+          if (fl > 0.f) {   // a per-env value of zero leaves the dof without the row
+            const float imp = impedance(R.d_solimp, 0.f, 0.f);
+            const float rR = fmaxf(MINVAL, (1.f - imp) * dinvw / imp);
+            fD = 1.f / rR; fRf = rR * fl; fls = fl;
+            faref = -R.d_solref[1] * vel;   // K = 0 for friction-loss rows
+          }
+          const auto& B = dm.rec[R.d_body];
+          if (B.b_jtype == CS_JNT_HINGE && B.j_limited) {
+            const float q = S.qpos[B.b_qadr];
+            const float dlo = q - B.j_range[0], dhi = B.j_range[1] - q;
+            lo_v = dlo < B.j_margin;
+            hi_v = dhi < B.j_margin;
+            if (lo_v || hi_v) {
+              // (both sides inside the margin at once needs margin > range / 2: the lower one is kept, the other counted as left out)
+              const float pos = lo_v ? dlo : dhi;
+              lsg = lo_v ? 1.f : -1.f;
+              const float imp = impedance(B.j_solimp, pos, B.j_margin);
+              const float rR = fmaxf(MINVAL, (1.f - imp) * dinvw / imp);
+              lD = 1.f / rR;
+              laref = -B.j_solref[1] * (lsg * vel) - B.j_solref[0] * imp * (pos - B.j_margin);
+            }
+          }
         }
-        unsigned long long ml = grp_ballot<LW>(lo_v, hb), mh = grp_ballot<LW>(hi_v, hb);
-        int rlo = __popcll(ml & lanemask_lt(ln)), rhi = __popcll(ml) + __popcll(mh & lanemask_lt(ln));
+        const unsigned long long ml = grp_ballot<LW>(lo_v, hb), mh = grp_ballot<LW>(hi_v, hb);
         nl = __popcll(ml) + __popcll(mh);
-        if (nl > L::NLIM) { st_droplim += nl - L::NLIM; nl = L::NLIM; }
-        if (lo_v && rlo < L::NLIM) { S.lim_body[rlo] = ln; S.lim_sign[rlo] = 1.f; S.lim_dist[rlo] = dlo; }
-        if (hi_v && rhi < L::NLIM) { S.lim_body[rhi] = ln; S.lim_sign[rhi] = -1.f; S.lim_dist[rhi] = dhi; }
+        st_droplim += __popcll(ml & mh);
       }
       {
         // capacity (MuJoCo's arena holds every contact; here the slots are sized per kernel variant): whatever does not fit is
         // left out in detection order AND counted -- meta[8] / solver_stats()["dropped_contacts"] is non-zero whenever an env
         // was stepped with a truncated constraint set
         const int ncon_all = ncon + npc;
-        int room = (MAXROWS - ne - nf - nl) / 4;
+        int room = (MAXROWS - ne) / 4;
         if (room < 0) room = 0;
         if constexpr (CT) {   // ground contacts: slots only; robot-robot contacts: slots and dense rows
           if (ncon > MC) ncon = MC;
@@ -1605,20 +1626,18 @@ __global__ __launch_bounds__(64, (EPW == 2 ? 2 : (163840 / (int)sizeof(typename 
         st_maxcon = max(st_maxcon, ncon_all);
       }
       const int ndc = CT ? npc : ncon;      // contacts with dense rows
-      const int ngen = ne + 4 * ndc;        // general rows (dense J): equality + contact
-      const int nrow = ngen + nf + nl;      // then unit rows (frictionloss, limits): the rows that live one per lane slot
-      const int nefc = nrow + (CT ? 4 * ncon : 0);   // CT: + the ground contacts' rows (twist space, not lane slots)
+      const int ngen = ne + 4 * ndc;        // dense rows (J row in LDS, one per lane slot): equality + contact
+      const int nefc = ngen + nf + nl + (CT ? 4 * ncon : 0);   // + the dof rows, + (CT) the ground contacts' rows in twist space
       WSYNC();
 
-      // per-lane row state: row (ln + LW rr), rr < RPL
-      int rtype[RPL], rdof[RPL];
-      // rlo < x < rhi: the row's quadratic zone in x = J a - aref (equality: all x; frictionloss: |x| < R f; limit / contact:
-      // x < 0); outside it the cost is linear with slope -+rfloss (0 for limit / contact) and offset rh0 = -R f^2 / 2
-      float rsign[RPL], rfloss[RPL], rD[RPL], rlo[RPL], rhi[RPL], rh0[RPL], raref[RPL], rpos_dbg = 0.f;
+      // per-lane dense row state: row (ln + LW rr), rr < RPL
+      bool rdense[RPL];
+      // x < rhi: the row's quadratic zone in x = J a - aref (equality: all x; contact: x < 0); beyond it the cost is zero
+      float rD[RPL], rhi[RPL], raref[RPL], rpos_dbg = 0.f;
 #pragma unroll
       for (int rr = 0; rr < RPL; rr++) {
         const int row = ln + LW * rr;
-        rtype[rr] = RT_NONE; rdof[rr] = 0; rsign[rr] = 1.f; rfloss[rr] = 0.f; rD[rr] = 0.f; rlo[rr] = -3.0e38f; rhi[rr] = 3.0e38f; rh0[rr] = 0.f; raref[rr] = 0.f;
+        rdense[rr] = row < ngen; rD[rr] = 0.f; rhi[rr] = 3.0e38f; raref[rr] = 0.f;
         float rpos = 0.f, rmargin = 0.f, rdiagA = 0.f, rmu = 0.f, rvel = 0.f;
         float rsolref[2] = {0.f, 0.f} /* (K, B) */, rsolimp[5] = {0.9f, 0.95f, 0.001f, 0.5f, 2.f};
         if (row < ngen) {
@@ -1628,8 +1647,8 @@ __global__ __launch_bounds__(64, (EPW == 2 ? 2 : (163840 / (int)sizeof(typename 
           // equality and contact rows share one Jacobian loop: J = +jac(chain A, point A) - jac(chain B, point B) along `dir`
           float dir[3], offA[3], offB[3];
           unsigned maskA, maskB;
-          if (row < ne) {
-            rtype[rr] = RT_EQ;
+          const bool is_eq = row < ne;
+          if (is_eq) {
             const int e = row / 3, comp = row - 3 * e;
             const auto& E = dm.rec[e];
             const int b1 = E.e_body1, b2 = E.e_body2;
@@ -1647,7 +1666,6 @@ __global__ __launch_bounds__(64, (EPW == 2 ? 2 : (163840 / (int)sizeof(typename 
             for (int k = 0; k < 2; k++) rsolref[k] = E.e_solref[k];
             for (int k = 0; k < 5; k++) rsolimp[k] = E.e_solimp[k];
           } else {
-            rtype[rr] = RT_CONTACT;
             const int c = (row - ne) >> 2, edge = (row - ne) & 3;
             const int gg = con_geom<CT>(S, !CT, c, c), g = gg & 0xff, g1 = (gg >> 8) - 1;   // g1 < 0: geom1 is the ground (CT: dense rows are robot-robot contacts)
             const auto& G = dm.rec[g];
@@ -1685,42 +1703,12 @@ __global__ __launch_bounds__(64, (EPW == 2 ? 2 : (163840 / (int)sizeof(typename 
               rvel += v * S.qvel[j];   // J qvel over the dofs the row touches
             }
           }
-        } else if (row < nrow) {
-          if (row < ngen + nf) {
-            rtype[rr] = RT_FRIC;
-            rdof[rr] = dm.rec[row - ngen].d_fric;  // model-level list; a per-env value of zero leaves the row inert
-            const auto& D = dm.rec[rdof[rr]];
-            rfloss[rr] = S.p_floss[rdof[rr]];
-            rdiagA = S.p_dinvw[rdof[rr]];
-            for (int k = 0; k < 2; k++) rsolref[k] = D.d_solref[k];
-            for (int k = 0; k < 5; k++) rsolimp[k] = D.d_solimp[k];
-            if (!(rfloss[rr] > 0.f)) { rtype[rr] = RT_NONE; rfloss[rr] = 0.f; }
-          } else {
-            rtype[rr] = RT_LIMIT;
-            const int li = row - ngen - nf;
-            const int b = S.lim_body[li];
-            const auto& B = dm.rec[b];
-            rdof[rr] = B.b_dadr;
-            rsign[rr] = S.lim_sign[li];
-            rpos = S.lim_dist[li];
-            rmargin = B.j_margin;
-            rdiagA = S.p_dinvw[rdof[rr]];
-            for (int k = 0; k < 2; k++) rsolref[k] = B.j_solref[k];
-            for (int k = 0; k < 5; k++) rsolimp[k] = B.j_solimp[k];
-          }
-        }
-        // KBIP, R, D, aref
-        if (rtype[rr] != RT_NONE) {
-          float imp = impedance(rsolimp, rpos, rmargin);
-          float K = rsolref[0], B = rsolref[1];   // stiffness and damping of the reference acceleration, precomputed on the host
-          if (rtype[rr] == RT_FRIC) K = 0.f;
+          // KBIP, R, D, aref (mj_makeImpedance; K and B precomputed on the host)
+          const float imp = impedance(rsolimp, rpos, rmargin);
           float rR = fmaxf(MINVAL, (1.f - imp) * rdiagA / imp);
-          if (rtype[rr] == RT_CONTACT) { float mu = rmu * rsqrtf(fmaxf(MINVAL, dm.impratio)); rR = 2.f * mu * mu * rR; }
+          if (!is_eq) { const float mu = rmu * rsqrtf(fmaxf(MINVAL, dm.impratio)); rR = 2.f * mu * mu * rR; rhi[rr] = 0.f; }   // contact: quadratic for x < 0, zero beyond
           rD[rr] = 1.f / rR;
-          if (rtype[rr] == RT_FRIC) { const float Rf = rR * rfloss[rr]; rlo[rr] = -Rf; rhi[rr] = Rf; rh0[rr] = -0.5f * Rf * rfloss[rr]; }
-          else if (rtype[rr] != RT_EQ) rhi[rr] = 0.f;   // limit, contact: quadratic for x < 0, zero beyond
-          const float vel = (rtype[rr] == RT_EQ || rtype[rr] == RT_CONTACT) ? rvel : rsign[rr] * S.qvel[rdof[rr]];
-          raref[rr] = -B * vel - K * imp * (rpos - rmargin);
+          raref[rr] = -rsolref[1] * rvel - rsolref[0] * imp * (rpos - rmargin);
         }
         if (rr == 0) rpos_dbg = rpos;
       }
@@ -1794,17 +1782,17 @@ __global__ __launch_bounds__(64, (EPW == 2 ? 2 : (163840 / (int)sizeof(typename 
         }
         return s;
       };
-      auto rowdot = [&](const float* v, int rr) -> float {  // J[row] . v for row (ln + LW rr)
+      auto rowdot = [&](const float* v, int rr) -> float {  // J[row] . v for dense row (ln + LW rr)
         float s = 0.f;
-        if (rtype[rr] == RT_EQ || rtype[rr] == RT_CONTACT) {
+        if (rdense[rr]) {
           const float* Jr = S.J[ln + LW * rr];
 #pragma unroll
           for (int d = 0; d < NV; d++) s += Jr[d] * v[d];
-        } else if (rtype[rr] == RT_FRIC || rtype[rr] == RT_LIMIT) s = rsign[rr] * v[rdof[rr]];
+        }
         return s;
       };
 #pragma unroll
-      for (int rr = 0; rr < RPL; rr++) { Jaref[rr] = rtype[rr] == RT_NONE ? 0.f : rowdot(S.qacc, rr) - raref[rr]; Jv[rr] = 0.f; }
+      for (int rr = 0; rr < RPL; rr++) { Jaref[rr] = rdense[rr] ? rowdot(S.qacc, rr) - raref[rr] : 0.f; Jv[rr] = 0.f; }
       Ma = mulM(S.qacc);
       float qacc_l = ln < NV ? S.qacc[ln] : 0.f;
       const float qsm_l = ln < NV ? S.qsm[ln] : 0.f;
@@ -1819,12 +1807,13 @@ __global__ __launch_bounds__(64, (EPW == 2 ? 2 : (163840 / (int)sizeof(typename 
       int cact_cur[CPL], cact_fac[CPL];    // CT: active edges (4 bits) of this lane's ground contacts now / at the last factorisation
 #pragma unroll
       for (int cc = 0; cc < CPL; cc++) { cact_cur[cc] = 0; cact_fac[cc] = -1; }
+      int uact_cur = 0, uact_fac = -1;     // dof rows of this lane inside their quadratic zone (bit 0 friction loss, bit 1 limit) now / at the last factorisation
+      float dofD_l = 0.f;                  // their active D: this dof's diagonal term of J^T D J
       unsigned cbmask = 0u;
       if constexpr (CT) cbmask = S.cbmask;
       auto update_constraint = [&]() {
         // mj_constraintUpdate: force, active set, cost
         float csum = 0.f;
-        if (ln < NV) { S.dofD[ln] = 0.f; S.qcon[ln] = 0.f; }
         if constexpr (CT) {
           if (ln < nbody) {
 #pragma unroll
@@ -1833,26 +1822,32 @@ __global__ __launch_bounds__(64, (EPW == 2 ? 2 : (163840 / (int)sizeof(typename 
         }
 #pragma unroll
         for (int rr = 0; rr < RPL; rr++) {
-          // branch-free over the row kinds (lanes of one wave hold different kinds): rows of kind NONE carry D = 0, f = 0
+          // branch-free (lanes past the last row carry D = 0): quadratic for x < rhi, zero beyond
           const float x = Jaref[rr];
-          const bool inq = x > rlo[rr] && x < rhi[rr];
-          const float sf = x <= rlo[rr] ? rfloss[rr] : -rfloss[rr];          // force on the linear branches (0 for limit / contact)
-          const float f = inq ? -rD[rr] * x : sf;
-          const float c = inq ? 0.5f * rD[rr] * x * x : rh0[rr] - sf * x;
+          const bool inq = x < rhi[rr];
           const float dact = inq ? rD[rr] : 0.f;
           dact_cur[rr] = dact;
-          csum += c;
-          S.w.r.rowf[ln + LW * rr] = f;
+          csum += 0.5f * dact * x * x;
+          S.w.r.rowf[ln + LW * rr] = -dact * x;
           S.w.r.rowD[ln + LW * rr] = dact;
         }
-        WSYNC();
-#pragma unroll
-        for (int rr = 0; rr < RPL; rr++)
-          if (rtype[rr] == RT_FRIC || rtype[rr] == RT_LIMIT) {
-            atomicAdd(&S.dofD[rdof[rr]], dact_cur[rr]);
-            atomicAdd(&S.qcon[rdof[rr]], rsign[rr] * S.w.r.rowf[ln + LW * rr]);
-          }
+        // dof rows: friction loss (Huber: quadratic for |x| < R f, linear with slope -+f beyond) and limit (one-sided quadratic);
+        // x = J a - aref straight from this lane's qacc
+        float qcu;   // their force on this dof
+        {
+          const float xf = qacc_l - faref;
+          const bool inf_ = fabsf(xf) < fRf;
+          const float sf = xf <= -fRf ? fls : -fls;
+          csum += inf_ ? 0.5f * fD * xf * xf : -0.5f * fRf * fls - sf * xf;
+          const float xl = lsg * qacc_l - laref;
+          const bool inl = xl < 0.f && lD > 0.f;
+          csum += inl ? 0.5f * lD * xl * xl : 0.f;
+          qcu = (inf_ ? -fD * xf : sf) + (inl ? -lsg * lD * xl : 0.f);
+          dofD_l = (inf_ ? fD : 0.f) + (inl ? lD : 0.f);
+          uact_cur = (inf_ ? 1 : 0) | (inl ? 2 : 0);
+        }
         if constexpr (CT) {
+          WSYNC();   // the bodies' wrenches are zero before the contacts add to them
           // ground contacts: one-sided quadratic rows (active while J a - aref < 0); their forces as one wrench per body
 #pragma unroll
           for (int cc = 0; cc < CPL; cc++) {
@@ -1887,7 +1882,7 @@ __global__ __launch_bounds__(64, (EPW == 2 ? 2 : (163840 / (int)sizeof(typename 
         WSYNC();
         float qc = 0.f;
         if (ln < NV) {
-          qc = S.qcon[ln];
+          qc = qcu;
           for (int r = 0; r < ngen; r++) qc += S.J[r][ln] * S.w.r.rowf[r];
           if constexpr (CT) {
             // J^T f of the ground contacts: cdof . (sum of the wrenches on the bodies this dof moves)
@@ -1921,6 +1916,7 @@ __global__ __launch_bounds__(64, (EPW == 2 ? 2 : (163840 / (int)sizeof(typename 
         for (int rr = 0; rr < RPL; rr++) changed = changed || (dact_cur[rr] != dact_fac[rr]);
 #pragma unroll
         for (int cc = 0; cc < CPL; cc++) changed = changed || (CT && cact_cur[cc] != cact_fac[cc]);
+        changed = changed || uact_cur != uact_fac;
         changed = changed && act;
         unsigned long long q0_ = 0;
         if (PROF) { __builtin_amdgcn_s_waitcnt(0); q0_ = __builtin_amdgcn_s_memtime(); }
@@ -1930,6 +1926,7 @@ __global__ __launch_bounds__(64, (EPW == 2 ? 2 : (163840 / (int)sizeof(typename 
           for (int rr = 0; rr < RPL; rr++) dact_fac[rr] = dact_cur[rr];
 #pragma unroll
           for (int cc = 0; cc < CPL; cc++) cact_fac[cc] = cact_cur[cc];
+          uact_fac = uact_cur;
           static_assert(NV <= 32, "one 32x32 MFMA tile");
           if constexpr (EPW == 1) {
              // H = M + (D J)^T J on the matrix pipe: v_mfma_f32_32x32x2_f32, two constraint rows per instruction
@@ -1985,9 +1982,9 @@ __global__ __launch_bounds__(64, (EPW == 2 ? 2 : (163840 / (int)sizeof(typename 
           if (PROF) { __builtin_amdgcn_s_waitcnt(0); unsigned long long t_ = __builtin_amdgcn_s_memtime(); pacc[10] += t_ - q0_; q0_ = t_; }   // Hessian build
           float a_row[NV];
           {
-            // unit rows (frictionloss, limits) only touch the diagonal: added in LDS (one dynamic access) so that the row
+            // dof rows (frictionloss, limits) only touch the diagonal: added in LDS (one dynamic access) so that the row
             // comes out as plain reads; lanes past NV factor a copy of row 0, which nobody reads
-            if (ln < NV) S.u.H[ln][ln] += S.dofD[ln];
+            if (ln < NV) S.u.H[ln][ln] += dofD_l;
             unsigned long long th0_ = 0;
             if constexpr (CT) {
               // J^T D J of the active ground-contact rows: per body the 6 x 6 matrix sum_e D w_e w_e^T (lower triangle), then through
@@ -2086,7 +2083,7 @@ __global__ __launch_bounds__(64, (EPW == 2 ? 2 : (163840 / (int)sizeof(typename 
         if (ln < nbody) { for (int k = 0; k < 3; k++) D[64 + ln * 3 + k] = S.xpos[ln][k]; for (int k = 0; k < 4; k++) D[192 + ln * 4 + k] = S.xquat[ln][k]; }
         for (int e = ln; e < TRI; e += LW) D[512 + e] = S.M[dm.tri_row[e]][dm.tri_col[e]];
         if (ln < NV) { D[1100 + ln] = S.qsm[ln]; for (int q = 0; q < 6; q++) D[1200 + ln * 6 + q] = S.cdof[ln][q]; }
-        D[1400 + ln] = (float)rtype[0]; D[1464 + ln] = rD[0]; D[1528 + ln] = raref[0]; D[1592 + ln] = rpos_dbg; D[1656 + ln] = Jaref[0];
+        D[1400 + ln] = rdense[0] ? (ln < ne ? (float)RT_EQ : (float)RT_CONTACT) : (float)RT_NONE; D[1464 + ln] = rD[0]; D[1528 + ln] = raref[0]; D[1592 + ln] = rpos_dbg; D[1656 + ln] = Jaref[0];
         if (ln < ngen) for (int d = 0; d < NV; d++) D[2048 + ln * NV + d] = S.J[ln][d];
         if (ln < MC && ln < 16) { D[1720 + ln] = ln < ncon ? S.cdist[ln] : 0.f; for (int k = 0; k < 3; k++) D[1740 + ln * 3 + k] = ln < ncon ? S.cpos[ln][k] : 0.f;
                        D[1900 + ln] = ln < ncon ? (float)S.cgeom[ln] : -1.f;
@@ -2118,6 +2115,7 @@ __global__ __launch_bounds__(64, (EPW == 2 ? 2 : (163840 / (int)sizeof(typename 
           Jv[rr] = rowdot(S.sr, rr);
           q0[rr] = 0.5f * rD[rr] * Jaref[rr] * Jaref[rr]; q1[rr] = rD[rr] * Jaref[rr] * Jv[rr]; q2[rr] = 0.5f * rD[rr] * Jv[rr] * Jv[rr];
         }
+        const float xf0 = qacc_l - faref, xl0 = lsg * qacc_l - laref, vl = lsg * sr_l;   // dof rows: J a - aref now, J s = +-s_dof
         if constexpr (CT) {
           // J s of the ground contacts from the bodies' twists of the search direction
           body_twists(S.sr, nullptr, S.tw, nullptr);
@@ -2143,12 +2141,22 @@ __global__ __launch_bounds__(64, (EPW == 2 ? 2 : (163840 / (int)sizeof(typename 
           float c0 = 0.f, c1 = 0.f, c2 = 0.f;
 #pragma unroll
           for (int rr = 0; rr < RPL; rr++) {
-            const float x = Jaref[rr] + alpha * Jv[rr];
-            const bool inq = x > rlo[rr] && x < rhi[rr];
-            const float sf = x <= rlo[rr] ? rfloss[rr] : -rfloss[rr];
-            c0 += inq ? q0[rr] : rh0[rr] - sf * Jaref[rr];
-            c1 += inq ? q1[rr] : -sf * Jv[rr];
+            const bool inq = Jaref[rr] + alpha * Jv[rr] < rhi[rr];
+            c0 += inq ? q0[rr] : 0.f;
+            c1 += inq ? q1[rr] : 0.f;
             c2 += inq ? q2[rr] : 0.f;
+          }
+          {
+            const float xf = xf0 + alpha * sr_l;
+            const bool inf_ = fabsf(xf) < fRf;
+            const float sf = xf <= -fRf ? fls : -fls;
+            c0 += inf_ ? 0.5f * fD * xf0 * xf0 : -0.5f * fRf * fls - sf * xf0;
+            c1 += inf_ ? fD * xf0 * sr_l : -sf * sr_l;
+            c2 += inf_ ? 0.5f * fD * sr_l * sr_l : 0.f;
+            const float dl = (xl0 + alpha * vl < 0.f) ? lD : 0.f;
+            c0 += 0.5f * dl * xl0 * xl0;
+            c1 += dl * xl0 * vl;
+            c2 += 0.5f * dl * vl * vl;
           }
           if constexpr (CT) {
 #pragma unroll
