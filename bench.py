@@ -22,10 +22,10 @@ import os
 import sys
 import time
 
-# The fleet is stepped as S range launches on S HIP streams (see --streams).  The HIP runtime maps streams onto 4 hardware queues by
-# default, and streams that share a queue run their kernels one after the other: 4 range streams + torch's own stream then step at
-# HALF the speed of 2 (measured 7.7 M vs 13.5 M env-steps/s).  Eight queues let the four ranges overlap (13.9 M).  Must be set before
-# the first HIP call of the process; the ranks of --gpus N inherit it.
+# The fleet is stepped as S range launches on S engine-owned HIP streams (see --streams).  The HIP runtime maps streams onto 4 hardware
+# queues by default, and streams that share a queue run their kernels one after the other: 4 range streams + torch's own stream then
+# step at HALF the speed of 2 (measured 7.7 M vs 13.5 M env-steps/s).  Eight queues let the four ranges overlap (13.9 M).  Must be set
+# before the first HIP call of the process; the ranks of --gpus N inherit it.  (cosim_amd/__init__.py does the same for any caller.)
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 import numpy as np
@@ -217,8 +217,11 @@ def main(argv=None):
     ap.add_argument("--workload", default="light_flat", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--streams", type=int, default=4,
-                    help="issue each control step of the per-GPU fleet as S launches over contiguous env ranges on S HIP streams "
-                         "(cosim_step_range: a range's next control step fills the tail of the others' launches); 1 = one launch")
+                    help="env.step() issues each control step of the per-GPU fleet as S launches over contiguous env ranges on S "
+                         "engine-owned HIP streams (BatchedEnv(ranges=S, deferred_join=True): a range's next control step fills the tail "
+                         "of the others' launches); 1 = one launch on the caller's stream")
+    ap.add_argument("--caller-streams", action="store_true",
+                    help="A/B: the round-2 arrangement, the CALLER builds the S streams and calls env.step_range per range")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse ranks on one GPU)")
     ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses cuda:0 (with --backend gloo)")
     ap.add_argument("--report-every", type=int, default=16, help="reporter statistics are sampled every this many timed steps")
@@ -255,13 +258,21 @@ def main(argv=None):
     cfg = make_config(robot, terrain=terrain, num_envs=n, seed=1234, height_map=hmap, position_command=poscmd)
     if poscmd:
         cfg["observation"]["command_dim"] = 2                        # envs/wrappers.py:357
-    # ONE fleet (one engine handle, one set of [N, ...] buffers).  S = 1: one launch per control step.  S > 1: the step is issued
-    # as S launches over contiguous env ranges (cosim_step_range), each range on its own HIP stream, so a range's next control
-    # step fills the tail of the others' launches (a launch ends with its slowest env; envs never interact).
-    env = BatchedEnv(cfg, num_envs=n, device=local, seed=1234, auto_reset=True, env_id0=env_id0, gain_noise=0.1)
+    # ONE fleet (one engine handle, one set of [N, ...] buffers), stepped with the plain env.step(action) of the drop-in API.
+    # S = 1: one launch per control step.  S > 1: the engine issues the step as S launches over contiguous env ranges, each range
+    # on an engine-owned HIP stream, and (deferred join) does not make the caller's stream wait for them, so a range's next control
+    # step fills the tail of the others' launches (a launch ends with its slowest env; envs never interact).  The actions are a
+    # table resident in HBM: nothing between two steps depends on the whole fleet's last state.
+    eng_ranges = 1 if args.caller_streams else S
+    env = BatchedEnv(cfg, num_envs=n, device=local, seed=1234, auto_reset=True, env_id0=env_id0, gain_noise=0.1,
+                     ranges=eng_ranges, deferred_join=eng_ranges > 1)
     envs = [env]
     main = torch.cuda.current_stream(env.device)
-    streams = [main] if S == 1 else [torch.cuda.Stream(device=env.device) for _ in range(S)]
+    if args.caller_streams:
+        streams = [main] if S == 1 else [torch.cuda.Stream(device=env.device) for _ in range(S)]
+    else:
+        ranges = list(env.range_list)
+        streams = [main] if S == 1 else list(env.range_streams)
     nu = env.action_dim
     total_steps = args.warmup + args.steps
     actions = synthetic_actions(n, env_id0, total_steps, nu, env.device)
@@ -280,14 +291,24 @@ def main(argv=None):
 
     def fleet_step(t, report):
         a = actions[t]
-        for i in range(S):
-            with torch.cuda.stream(streams[i]):
-                env.step_range(ranges[i][0], ranges[i][1], a)
-                if report:   # reporter statistics of this step: each range's info rows are reduced on that range's own stream
+        if args.caller_streams:
+            for i in range(S):
+                with torch.cuda.stream(streams[i]):
+                    env.step_range(ranges[i][0], ranges[i][1], a)
+                    if report:
+                        reporter.write_info_range(ranges[i][0], ranges[i][1])
+            return
+        env.step(a)
+        if report:   # reporter statistics of this step: each range's info rows are reduced on that range's own stream
+            for i in range(S):
+                with torch.cuda.stream(streams[i]):
                     reporter.write_info_range(ranges[i][0], ranges[i][1])
+                if S > 1:
+                    env.range_mark(i)
 
-    for st_ in streams:
-        st_.wait_stream(main)
+    if args.caller_streams:
+        for st_ in streams:
+            st_.wait_stream(main)
     for t in range(args.warmup):
         fleet_step(t, t == 0)             # t == 0: warm-up of the reducer (first use loads code objects: ~100 ms)
     torch.cuda.synchronize()
@@ -306,10 +327,16 @@ def main(argv=None):
     t0 = time.perf_counter()
     for t in range(args.warmup, total_steps):
         fleet_step(t, (t - args.warmup) % args.report_every == 0)   # sampled: first timed step, then every k-th
+    t_issue = time.perf_counter()
+    env.join()                                          # the deferred join: the caller's stream now waits for every range
     torch.cuda.synchronize()
+    t_gpu = time.perf_counter()
     fleet = reporter.acc.reduce()                       # the one collective: RCCL all-reduce of (count, sum, sum^2)
     sync()
     dt = time.perf_counter() - t0
+    if os.environ.get("COSIM_BENCH_TRACE"):             # diagnostic: where the timed region's wall time went
+        print(f"[bench trace] issue loop {1e3 * (t_issue - t0):.3f} ms, + join/sync {1e3 * (t_gpu - t_issue):.3f} ms, + reduce/sync "
+              f"{1e3 * (t0 + dt - t_gpu):.3f} ms", file=sys.stderr, flush=True)
     kt = [e.engine.kernel_time() for e in envs]
     launches = sum(k[1] for k in kt)
     kernel_ms = sum(k[0] * k[1] for k in kt) / max(1, launches)
@@ -342,7 +369,11 @@ def main(argv=None):
                        "solver_per_substep": {"rows": st["rows"] / nsub, "newton_iters": st["newton_iters"] / nsub,
                                               "ls_evals": st["ls_evals"] / nsub, "factorisations": st["factorisations"] / nsub},
                        "nan_resets": st["nan_resets"], "dropped_contacts": st["dropped_contacts"], "dropped_limit_rows": st["dropped_limit_rows"],
-                       "max_contacts_per_env": max(x["max_contacts"] for x in sts), "contact_slots": env.engine.query("contact_slots")},
+                       "max_contacts_per_env": max(x["max_contacts"] for x in sts), "contact_slots": env.engine.query("contact_slots"),
+                       # control steps redone by the large-capacity kernel (contacts beyond the fleet kernel's slots); 0 slots: the
+                       # workload's kernel has no such sibling and counts what it leaves out in dropped_contacts
+                       "fixup_steps": st["fixup_steps"], "fixup_contact_slots": env.engine.query("fixup_contact_slots"),
+                       "step_api": "caller streams + env.step_range" if args.caller_streams else "env.step"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, **pmc_traffic(args.workload),
                          # per launch as the contract defines it (S launches overlap on the chip); the whole fleet per control step:

@@ -54,7 +54,14 @@ class _Data:
 
 class BatchedEnv:
     def __init__(self, config: dict, num_envs: Optional[int] = None, device: Optional[int] = None, seed: Optional[int] = None,
-                 auto_reset: bool = True, env_id0: int = 0, gain_noise: float = 0.0, compiled: Optional[CompiledModel] = None):
+                 auto_reset: bool = True, env_id0: int = 0, gain_noise: float = 0.0, compiled: Optional[CompiledModel] = None,
+                 ranges: Optional[int] = None, deferred_join: Optional[bool] = None):
+        """``ranges`` > 1: ``step()`` issues the fleet as that many launches over contiguous env ranges on engine-owned HIP streams
+        (``cosim_set_param "ranges"``).  With ``deferred_join`` the caller's stream is NOT made to wait for them inside ``step()``:
+        call ``join()`` before consuming ``state`` / ``terminated`` / ``info`` on the current stream (``get_data``, ``reset``,
+        ``event``, ``set_state`` and ``solver_stats`` join by themselves).  That is what lets a range's next control step overlap
+        the tail of the others' current one; it fits callers whose next action does not need the whole fleet's last state (an
+        action table; a policy evaluated per range on ``range_streams``).  Defaults: ``config["engine"]`` / 1 / False."""
         import torch  # plumbing only
 
         eng_cfg = config.get("engine", {})
@@ -121,6 +128,20 @@ class BatchedEnv:
                 self.engine.set_param("envs_per_wave", np.array([float(epw)]))
             except (ValueError, RuntimeError):
                 pass
+
+        self.ranges = int(ranges if ranges is not None else os.environ.get("COSIM_RANGES", eng_cfg.get("ranges", 1)))
+        self.ranges = max(1, min(self.ranges, self.num_envs, 16))
+        self.deferred_join = bool(deferred_join if deferred_join is not None else eng_cfg.get("deferred_join", False))
+        self.range_list = [(0, self.num_envs)]
+        self.range_streams = [None]
+        if self.ranges > 1:
+            self.engine.set_param("ranges", np.array([float(self.ranges)]))
+            self.engine.set_param("deferred_join", np.array([float(self.deferred_join)]))
+            if os.environ.get("COSIM_INFLIGHT"):               # steps the host may run ahead of each range stream (tuning runs)
+                self.engine.set_param("inflight", np.array([float(os.environ["COSIM_INFLIGHT"])]))
+            rl = [self.engine.range(i) for i in range(self.ranges)]
+            self.range_list = [(f, c) for f, c, _ in rl]
+            self.range_streams = [torch.cuda.ExternalStream(st, device=self.device) for _, _, st in rl]
 
         self._randomise(gain_noise)
 
@@ -220,22 +241,35 @@ class BatchedEnv:
         self.engine.step_range(first, count, action.data_ptr(), self._cmd_ptr(), self.state.data_ptr(), self.terminated.data_ptr(),
                                self.truncated.data_ptr(), self.info_buf.data_ptr(), self._stream())
 
+    def join(self):
+        """Deferred join: make the current stream wait for every range stream's work so far (``cosim_join``)."""
+        self.engine.join(self._stream())
+
+    def range_mark(self, i: int):
+        """After enqueuing work of your own on ``range_streams[i]``: the next ``join()`` waits for it too (``cosim_range_mark``)."""
+        self.engine.range_mark(i)
+
     def _info(self, action) -> Dict[str, object]:
         """Batched ``_get_info`` + ``user_command_i`` (flamingo_light_v1.py:166-183; wrappers.py:399-400)."""
-        nu, b = self.action_dim, self.info_buf
-        info = {
-            "dt": self.dt_ * self.frame_skip,
-            "action": action,
-            "action_diff_RMSE": b[:, 0],
-            "lin_vel_x": b[:, 1],
-            "lin_vel_y": b[:, 2],
-            "ang_vel_yaw": b[:, 3],
-            "torque": b[:, 4:4 + nu],
-            "set_points": b[:, 4 + nu:4 + 2 * nu],
-            "state": b[:, 4 + 2 * nu:],
-        }
-        for i in range(self.command_dim):
-            info[f"user_command_{i}"] = self.user_command[:, i]
+        info = getattr(self, "_info_views", None)
+        if info is None:   # views of the fleet's fixed buffers: built once, handed out every step (only "action" changes)
+            nu, b = self.action_dim, self.info_buf
+            info = {
+                "dt": self.dt_ * self.frame_skip,
+                "action": action,
+                "action_diff_RMSE": b[:, 0],
+                "lin_vel_x": b[:, 1],
+                "lin_vel_y": b[:, 2],
+                "ang_vel_yaw": b[:, 3],
+                "torque": b[:, 4:4 + nu],
+                "set_points": b[:, 4 + nu:4 + 2 * nu],
+                "state": b[:, 4 + 2 * nu:],
+            }
+            for i in range(self.command_dim):
+                info[f"user_command_{i}"] = self.user_command[:, i]
+            self._info_views = info
+        info = dict(info)
+        info["action"] = action
         return info
 
     def event(self, event: str, value, mask=None):
@@ -271,7 +305,7 @@ class BatchedEnv:
         """Cumulative solver counters since creation (fleet sums): control steps, constraint rows (summed over
         substeps), Newton iterations, line-search evaluations, Hessian factorisations, non-finite resets."""
         t = self.torch
-        buf = t.zeros((self.num_envs, 12), dtype=t.float32, device=self.device)
+        buf = t.zeros((self.num_envs, 16), dtype=t.float32, device=self.device)
         self.engine.get("meta", buf.data_ptr(), self._stream())
         t.cuda.synchronize(self.device)
         mi = buf.view(t.int32).to(t.int64)
@@ -280,7 +314,9 @@ class BatchedEnv:
         # max_contacts: most contacts detected in one substep by any env of the fleet
         return {"step_count": int(m[1]), "rows": int(m[3]), "nan_resets": int(m[4]), "newton_iters": int(m[5]),
                 "ls_evals": int(m[6]), "factorisations": int(m[7]), "dropped_contacts": int(m[8]), "dropped_limit_rows": int(m[9]),
-                "max_contacts": int(mi[:, 10].max().item()), "episodes_ended": int(m[11])}
+                "max_contacts": int(mi[:, 10].max().item()), "episodes_ended": int(m[11]),
+                # control steps redone by the large-capacity kernel because their contacts did not fit the fleet kernel's slots
+                "fixup_steps": int(m[12])}
 
     def render(self):
         pass  # headless

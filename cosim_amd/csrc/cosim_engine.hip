@@ -4,6 +4,8 @@
 // and launches the one-wave-per-env kernel (cosim_kernels.hip) specialised for the model's (nv, nbody).
 #include <math.h>
 #include <stdio.h>
+#include <stdlib.h>
+#include <time.h>
 #include <string.h>
 
 #include <string>
@@ -67,6 +69,26 @@ struct cosim_engine {
   int lds_bytes = 0;
   int geom_stage = 64;   // plane kernels: geom lanes that can stage their contacts
   int contact_slots = 0, pair_slots = 0;   // ground-contact / robot-robot contact capacity of the selected kernel
+  // large-capacity kernel behind the fleet kernel (env_fixup_kernel): redoes the control step of envs whose contacts did not fit
+  void (*launch_fix)(cosim_engine*, const KArgs&, int grid, hipStream_t) = nullptr;
+  int fix_contact_slots = 0;
+  int* d_ovf = nullptr;   // [n_envs] flags, set by the fleet kernel, cleared by the fix-up kernel
+  // range launches: cosim_step issues the fleet as n_ranges launches over contiguous env ranges on engine-owned streams, so that a
+  // range's next control step fills the tail of the others' launches (a launch ends with its slowest env)
+  int n_ranges = 1;
+  bool deferred_join = false;   // true: cosim_step does not make the caller's stream wait for the range streams (cosim_join does)
+  bool join_pending = false;
+  std::vector<hipStream_t> rstream;
+  std::vector<hipEvent_t> rdone;   // one per range: recorded after the range's last launch
+  hipEvent_t ev_in = nullptr;      // recorded on the caller's stream, waited on by the range streams: the step's inputs are ready
+  std::vector<int> rfirst, rcount;
+  // flow control of the range launches: the host stays at most `inflight` control steps ahead of each range (a ring of events per
+  // range; cosim_step blocks on the oldest).  Deep queues are slow on this runtime: with the host hundreds of steps ahead the four
+  // range chains step at 12.0 M env-steps/s, held to 2 ... 16 steps ahead at 13.6 ... 13.7 M (1: 13.35, 64: 13.3; MI355X, ROCm 7.2).
+  // Short runs gain most from a shallow queue (20 timed steps: 2 -> 12.9 M, 4 -> 12.4, 8 -> 12.2, 16 -> 11.4, unbounded 10.9).
+  int inflight = 2;   // 0: unbounded
+  std::vector<hipEvent_t> ring;   // [n_ranges][inflight]
+  long ring_pos = 0;
 };
 
 template <int NV, int NB, int RPL, bool HF, int GTM, bool SC, int MCT>
@@ -76,6 +98,10 @@ static void launch_t(cosim_engine* e, const KArgs& a, int grid, hipStream_t s) {
 template <int NV, int NB, int RPL, bool HF, int GTM, bool SC, int MCT>
 static void launch_prof_t(cosim_engine* e, const KArgs& a, int grid, hipStream_t s) {
   hipLaunchKernelGGL((env_kernel<NV, NB, RPL, HF, GTM, SC, true, 1, MCT>), dim3(grid), dim3(64), 0, s, a);
+}
+template <int NV, int NB, int RPL, bool HF, int GTM, bool SC, int MCT>
+static void launch_fix_t(cosim_engine* e, const KArgs& a, int grid, hipStream_t s) {   // grid = envs of the range
+  hipLaunchKernelGGL((env_fixup_kernel<NV, NB, RPL, HF, GTM, SC, MCT>), dim3((grid + 63) / 64), dim3(64), 0, s, a);
 }
 template <int NV, int NB, int GTM>
 static void launch2_t(cosim_engine* e, const KArgs& a, int grid, hipStream_t s) {   // grid = number of envs
@@ -344,6 +370,48 @@ static int upload_params(cosim_engine* e) {
   return COSIM_OK;
 }
 
+// n contiguous ranges of n_envs / n envs (the first n_envs % n one longer; even sizes for the two-envs-per-wave kernel), each with
+// a non-blocking stream of its own and a "done" event
+static int set_ranges(cosim_engine* e, int n) {
+  if (n < 1 || n > 16 || n > e->n_envs) return fail(COSIM_EINVAL, "cosim_set_param: ranges must be 1..16 and at most n_envs");
+  HIP_TRY(hipSetDevice(e->device));
+  for (hipStream_t x : e->rstream) { HIP_TRY(hipStreamSynchronize(x)); HIP_TRY(hipStreamDestroy(x)); }
+  for (hipEvent_t x : e->rdone) HIP_TRY(hipEventDestroy(x));
+  e->rstream.clear(); e->rdone.clear(); e->rfirst.clear(); e->rcount.clear();
+  e->join_pending = false;
+  e->n_ranges = n;
+  for (hipEvent_t x : e->ring) HIP_TRY(hipEventDestroy(x));
+  e->ring.clear();
+  e->ring_pos = 0;
+  for (int i = 0; i < n * e->inflight; i++) { hipEvent_t ev; HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming)); e->ring.push_back(ev); }
+  if (n == 1) return COSIM_OK;
+  if (!e->ev_in) HIP_TRY(hipEventCreateWithFlags(&e->ev_in, hipEventDisableTiming));
+  const int unit = e->epw == 2 ? 2 : 1, units = e->n_envs / unit;
+  int first = 0;
+  for (int i = 0; i < n; i++) {
+    int cnt = (units / n + (i < units % n ? 1 : 0)) * unit;
+    if (i == n - 1) cnt = e->n_envs - first;
+    hipStream_t st; hipEvent_t ev;
+    HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    e->rstream.push_back(st); e->rdone.push_back(ev); e->rfirst.push_back(first); e->rcount.push_back(cnt);
+    first += cnt;
+  }
+  return COSIM_OK;
+}
+
+// `stream` waits for everything the range streams have been given so far: the "done" events are recorded here, at join time (an
+// event marks everything enqueued before it), not after every range launch -- a deferred-join caller pays no marker packets per step
+static int join_ranges(cosim_engine* e, hipStream_t stream) {
+  if (!e->join_pending) return COSIM_OK;
+  for (int i = 0; i < e->n_ranges; i++) {
+    HIP_TRY(hipEventRecord(e->rdone[i], e->rstream[i]));
+    HIP_TRY(hipStreamWaitEvent(stream, e->rdone[i], 0));
+  }
+  e->join_pending = false;
+  return COSIM_OK;
+}
+
 extern "C" {
 
 // Fused actor MLP (cosim_mlp.hip): out = clip(act_L(... act_1(x W_1^T + b_1) ...)).  All pointers are device pointers; dims has
@@ -452,6 +520,10 @@ int cosim_create(const cosim_model_t* model, const float* hull_vert, const int* 
       e->launch_ct_prof = launch_prof_t<18, 14, 1, false, G_LIGHT, false, 32>;
       e->ct_lds_bytes = (int)sizeof(typename KTraits<18, 14, 1, false, false, 1, 32>::L);
       e->ct_contact_slots = 32;
+      // ... and with 40 slots (four per ground geom at most: 7 hulls, 2 cylinders, 4 spheres -> 40 is the most the plane narrowphase
+      // can emit) as the kernel that redoes the rare control step with more than 14 contacts: nothing is ever left out
+      e->launch_fix = launch_fix_t<18, 14, 1, false, G_LIGHT, false, 40>;
+      e->fix_contact_slots = 40;
     }
   }
   else if (nv == 14 && nb <= 10 && (gtm & ~G_MESH) == 0) {   // flamingo_p_v3
@@ -481,6 +553,8 @@ int cosim_create(const cosim_model_t* model, const float* hull_vert, const int* 
   HIP_TRY(hipMemset(e->d_state, 0, (size_t)n_envs * e->lay.s_stride * sizeof(float)));
   HIP_TRY(hipMalloc(&e->d_params, (size_t)n_envs * e->lay.p_stride * sizeof(float)));
   HIP_TRY(hipMalloc(&e->d_dbg, 8192 * sizeof(float)));
+  HIP_TRY(hipMalloc(&e->d_ovf, (size_t)n_envs * sizeof(int)));
+  HIP_TRY(hipMemset(e->d_ovf, 0, (size_t)n_envs * sizeof(int)));
   int nhv = model->nhullvert > 0 ? model->nhullvert : 1, nhe = model->nhulledge > 0 ? model->nhulledge : 1;
   HIP_TRY(hipMalloc(&e->d_hull_vert, (size_t)nhv * 4 * sizeof(float)));   // 16 bytes per vertex on the device: one load each
   HIP_TRY(hipMalloc(&e->d_hull_adr, (size_t)(nhv + 1) * sizeof(int)));
@@ -513,6 +587,7 @@ int cosim_create(const cosim_model_t* model, const float* hull_vert, const int* 
     HIP_TRY(hipMemcpy(e->d_hfield, hfield, nh * sizeof(float), hipMemcpyHostToDevice));
   }
   default_params(e);
+  { int rc2 = set_ranges(e, 1); if (rc2) return rc2; }   // (allocates the pacing events of the single-launch path)
   *out = e;
   return COSIM_OK;
 }
@@ -522,8 +597,11 @@ int cosim_destroy(cosim_engine_t* e) {
   hipSetDevice(e->device);
   hipFree(e->d_model); hipFree(e->d_obs); hipFree(e->d_state); hipFree(e->d_params); hipFree(e->d_dbg);
   hipFree(e->d_hull_vert); hipFree(e->d_hull_adr); hipFree(e->d_hull_nbr); hipFree(e->d_hfield);
-  hipFree(e->d_pairs); hipFree(e->d_gext);
+  hipFree(e->d_pairs); hipFree(e->d_gext); hipFree(e->d_ovf);
   for (hipEvent_t x : e->ev) hipEventDestroy(x);
+  for (hipStream_t x : e->rstream) hipStreamDestroy(x);
+  for (hipEvent_t x : e->rdone) hipEventDestroy(x);
+  if (e->ev_in) hipEventDestroy(e->ev_in);
   delete e;
   return COSIM_OK;
 }
@@ -544,6 +622,8 @@ int cosim_query(const cosim_engine_t* e, const char* name) {
   if (n == "param_stride") return e->lay.p_stride;
   if (n == "lds_bytes") return e->lds_bytes;
   if (n == "contact_slots") return e->contact_slots;
+  if (n == "fixup_contact_slots") return e->launch_fix ? e->fix_contact_slots : 0;   // 0: no large-capacity kernel behind this one
+  if (n == "ranges") return e->n_ranges;
   if (n == "pair_slots") return e->pair_slots;
   if (n == "stacked_dim") return e->ho.stacked_dim;
   if (n == "frame_dim") return e->ho.frame_dim;
@@ -574,10 +654,26 @@ int cosim_set_param(cosim_engine_t* e, const char* name, const float* host, int 
     return COSIM_OK;
   }
   else if (n == "debug_substeps") { e->nsub_override = (int)host[0]; return COSIM_OK; }
+  else if (n == "ranges") return set_ranges(e, (int)host[0]);
+  else if (n == "deferred_join") {   // 1: cosim_step leaves the join of the range streams to cosim_join (or to the next call that touches the state)
+    e->deferred_join = (int)host[0] != 0;
+    return COSIM_OK;
+  }
+  else if (n == "inflight") {   // control steps the host may run ahead of each range stream (0: unbounded)
+    const int v = (int)host[0];
+    if (v < 0 || v > 1024) return fail(COSIM_EINVAL, "cosim_set_param: inflight must be 0..1024");
+    e->inflight = v;
+    return set_ranges(e, e->n_ranges);
+  }
+  else if (n == "fixup") {   // 0: no fix-up launches (contacts beyond the fleet kernel's slots are left out and counted, as in round 2)
+    if ((int)host[0] == 0) e->launch_fix = nullptr;
+    return COSIM_OK;
+  }
   else if (n == "contact_twist") {   // 1: switch a dense-row kernel to its contact-twist variant (more contact slots), where one exists
     if ((int)host[0] != 0) {
       if (!e->launch_ct) return fail(COSIM_EINVAL, "cosim_set_param: no contact-twist variant for this model / terrain");
       e->launch = e->launch_ct; e->launch_prof = e->launch_ct_prof; e->launch2 = nullptr; e->launch_prof2 = nullptr; e->epw = 1;
+      e->launch_fix = nullptr;
       e->lds_bytes = e->ct_lds_bytes; e->contact_slots = e->ct_contact_slots;
     }
     return COSIM_OK;
@@ -588,7 +684,7 @@ int cosim_set_param(cosim_engine_t* e, const char* name, const float* host, int 
     const int w = (int)host[0];
     if (w != 1 && !(w == 2 && e->launch2 && e->n_envs % 2 == 0)) return fail(COSIM_EINVAL, "cosim_set_param: envs_per_wave not available for this model / env count");
     e->epw = w;
-    return COSIM_OK;
+    return e->n_ranges > 1 ? set_ranges(e, e->n_ranges) : COSIM_OK;   // (two envs per wave: even range sizes)
   }
   else return fail(COSIM_EINVAL, "cosim_set_param: unknown parameter " + n);
   if (count != e->n_envs * width) return fail(COSIM_EINVAL, "cosim_set_param: " + n + " expects n_envs*" + std::to_string(width) + " values");
@@ -619,6 +715,7 @@ static KArgs base_args(cosim_engine* e) {
   a.n_envs = e->n_envs; a.seed_lo = (unsigned)e->seed; a.seed_hi = (unsigned)(e->seed >> 32); a.env_id0 = e->env_id0;
   a.tol32 = e->tol32; a.ls_scale = e->ls_scale; a.max_newton = e->max_newton; a.max_ls = e->max_ls; a.nsub_override = e->nsub_override; a.pair_coop = e->pair_coop; a.pair_boxbox = e->pair_boxbox;
   for (int k = 0; k < 4; k++) a.prio[k] = e->prio[k];
+  a.ovf = nullptr;
   return a;
 }
 
@@ -626,6 +723,8 @@ int cosim_reset(cosim_engine_t* e, const uint8_t* mask_dev, const float* command
   if (!e || !state_out_dev) return fail(COSIM_EINVAL, "cosim_reset: null argument");
   HIP_TRY(hipSetDevice(e->device));
   int rc = upload_params(e);
+  if (rc) return rc;
+  rc = join_ranges(e, (hipStream_t)stream);
   if (rc) return rc;
   KArgs a = base_args(e);
   a.mode = MODE_RESET; a.mask = mask_dev; a.commands = commands_dev; a.state_out = state_out_dev;
@@ -637,7 +736,72 @@ int cosim_reset(cosim_engine_t* e, const uint8_t* mask_dev, const float* command
 int cosim_step(cosim_engine_t* e, const float* actions_dev, const float* commands_dev, float* state_out_dev, uint8_t* terminated_dev,
                uint8_t* truncated_dev, float* info_out_dev, void* stream) {
   if (!e) return fail(COSIM_EINVAL, "cosim_step: null argument");
-  return cosim_step_range(e, 0, e->n_envs, actions_dev, commands_dev, state_out_dev, terminated_dev, truncated_dev, info_out_dev, stream);
+  if (e->n_ranges <= 1) {   // one launch on the caller's stream, paced like the range launches below
+    HIP_TRY(hipSetDevice(e->device));
+    hipStreamCaptureStatus cap1 = hipStreamCaptureStatusNone;
+    HIP_TRY(hipStreamIsCapturing((hipStream_t)stream, &cap1));
+    const bool paced = e->inflight > 0 && cap1 == hipStreamCaptureStatusNone && (int)e->ring.size() >= e->inflight;
+    if (paced && e->ring_pos >= e->inflight) HIP_TRY(hipEventSynchronize(e->ring[e->ring_pos % e->inflight]));
+    int rc = cosim_step_range(e, 0, e->n_envs, actions_dev, commands_dev, state_out_dev, terminated_dev, truncated_dev, info_out_dev, stream);
+    if (rc) return rc;
+    if (paced) { HIP_TRY(hipEventRecord(e->ring[e->ring_pos % e->inflight], (hipStream_t)stream)); e->ring_pos++; }
+    return COSIM_OK;
+  }
+  // fork: the range streams wait for whatever the caller's stream has been given so far (the step's inputs), then each steps its
+  // range; join: the caller's stream waits for every range -- now, or (deferred_join) at the next cosim_join / state access, which
+  // is what lets a range's next control step overlap the tail of the others' current one
+  HIP_TRY(hipSetDevice(e->device));
+  hipStream_t cs = (hipStream_t)stream;
+  // The inputs are ready once everything given to the caller's stream so far has run.  If that stream is idle they are ready now, and
+  // the range streams need no wait: a cross-queue wait is a barrier packet ahead of every range launch (measured: 12.6 -> 11.0 M with
+  // an idle caller stream).  Not while capturing: a query is illegal there, and the fork edge is what ties the range streams in.
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  HIP_TRY(hipStreamIsCapturing(cs, &cap));
+  bool wait_in = true;
+  if (cap == hipStreamCaptureStatusNone) {
+    const hipError_t q = hipStreamQuery(cs);
+    if (q == hipSuccess) wait_in = false;
+    else if (q != hipErrorNotReady) return fail(COSIM_EHIP, std::string("hipStreamQuery: ") + hipGetErrorString(q));
+    (void)hipGetLastError();   // hipErrorNotReady is sticky in hipGetLastError
+  }
+  if (wait_in) HIP_TRY(hipEventRecord(e->ev_in, cs));
+  for (int i = 0; i < e->n_ranges; i++) {
+    if (wait_in) HIP_TRY(hipStreamWaitEvent(e->rstream[i], e->ev_in, 0));
+    // (not while capturing: a captured step is replayed, the host does not pace it)
+    const bool paced = e->inflight > 0 && cap == hipStreamCaptureStatusNone;
+    if (paced && e->ring_pos >= e->inflight)   // the step `inflight` steps back has left this range's stream
+      HIP_TRY(hipEventSynchronize(e->ring[(size_t)i * e->inflight + e->ring_pos % e->inflight]));
+    int rc = cosim_step_range(e, e->rfirst[i], e->rcount[i], actions_dev, commands_dev, state_out_dev, terminated_dev, truncated_dev, info_out_dev,
+                              e->rstream[i]);
+    if (rc) return rc;
+    if (paced) HIP_TRY(hipEventRecord(e->ring[(size_t)i * e->inflight + e->ring_pos % e->inflight], e->rstream[i]));
+  }
+  if (e->inflight > 0 && cap == hipStreamCaptureStatusNone) e->ring_pos++;
+  e->join_pending = true;
+  if (!e->deferred_join) return join_ranges(e, cs);
+  return COSIM_OK;
+}
+
+int cosim_join(cosim_engine_t* e, void* stream) {
+  if (!e) return fail(COSIM_EINVAL, "cosim_join: null engine");
+  HIP_TRY(hipSetDevice(e->device));
+  return join_ranges(e, (hipStream_t)stream);
+}
+
+int cosim_range(const cosim_engine_t* e, int i, int* first, int* count, void** stream) {
+  if (!e || i < 0 || i >= e->n_ranges) return fail(COSIM_EINVAL, "cosim_range: bad argument");
+  if (first) *first = e->n_ranges > 1 ? e->rfirst[i] : 0;
+  if (count) *count = e->n_ranges > 1 ? e->rcount[i] : e->n_envs;
+  if (stream) *stream = e->n_ranges > 1 ? (void*)e->rstream[i] : nullptr;
+  return COSIM_OK;
+}
+
+// After something was enqueued on range stream i from outside (a per-range policy, a reporter reduction): re-arm the range's "done"
+// event so that a later join also waits for that work.
+int cosim_range_mark(cosim_engine_t* e, int i) {
+  if (!e || i < 0 || i >= e->n_ranges || e->n_ranges <= 1) return fail(COSIM_EINVAL, "cosim_range_mark: bad argument");
+  e->join_pending = true;   // (the "done" events are recorded at join time: everything on the range stream by then is covered)
+  return COSIM_OK;
 }
 
 int cosim_step_range(cosim_engine_t* e, int first, int count, const float* actions_dev, const float* commands_dev, float* state_out_dev,
@@ -652,7 +816,8 @@ int cosim_step_range(cosim_engine_t* e, int first, int count, const float* actio
   KArgs a = base_args(e);
   a.mode = MODE_STEP; a.actions = actions_dev; a.commands = commands_dev; a.state_out = state_out_dev;
   a.terminated = terminated_dev; a.truncated = truncated_dev; a.info = info_out_dev;
-  a.env_first = first;
+  a.env_first = first; a.env_count = count;
+  a.ovf = (e->launch_fix && e->epw == 1) ? e->d_ovf : nullptr;
   hipStream_t s = (hipStream_t)stream;
   // kernel timing: one HIP event pair per launch on the launch stream, read back in cosim_kernel_time() (no sync here)
   int slot = -1;
@@ -668,6 +833,10 @@ int cosim_step_range(cosim_engine_t* e, int first, int count, const float* actio
   (e->epw == 2 ? e->launch2 : e->launch)(e, a, count, s);
   HIP_TRY(hipGetLastError());
   if (slot >= 0) HIP_TRY(hipEventRecord(e->ev[slot + 1], s));
+  if (a.ovf) {   // envs the fleet kernel flagged (more contacts than it has slots for) are redone by the large-capacity kernel
+    e->launch_fix(e, a, count, s);
+    HIP_TRY(hipGetLastError());
+  }
   return COSIM_OK;
 }
 
@@ -686,6 +855,8 @@ int cosim_get(cosim_engine_t* e, const char* name, float* out_dev, void* stream)
   int off, width;
   int rc = locate(e, name, &off, &width);
   if (rc) return rc;
+  rc = join_ranges(e, (hipStream_t)stream);
+  if (rc) return rc;
   HIP_TRY(hipMemcpy2DAsync(out_dev, width * sizeof(float), e->d_state + off, e->lay.s_stride * sizeof(float), width * sizeof(float),
                            e->n_envs, hipMemcpyDeviceToDevice, (hipStream_t)stream));
   return COSIM_OK;
@@ -696,6 +867,8 @@ int cosim_set(cosim_engine_t* e, const char* name, const float* in_dev, void* st
   HIP_TRY(hipSetDevice(e->device));
   int off, width;
   int rc = locate(e, name, &off, &width);
+  if (rc) return rc;
+  rc = join_ranges(e, (hipStream_t)stream);
   if (rc) return rc;
   HIP_TRY(hipMemcpy2DAsync(e->d_state + off, e->lay.s_stride * sizeof(float), in_dev, width * sizeof(float), width * sizeof(float),
                            e->n_envs, hipMemcpyDeviceToDevice, (hipStream_t)stream));
@@ -719,6 +892,7 @@ __global__ void push_kernel(float* state, Layout lay, const float* v, const uint
 int cosim_event_push(cosim_engine_t* e, const float* v_dev, const uint8_t* mask_dev, void* stream) {
   if (!e || !v_dev) return fail(COSIM_EINVAL, "cosim_event_push: null argument");
   HIP_TRY(hipSetDevice(e->device));
+  { int rc = join_ranges(e, (hipStream_t)stream); if (rc) return rc; }
   hipLaunchKernelGGL(push_kernel, dim3((e->n_envs + 255) / 256), dim3(256), 0, (hipStream_t)stream, e->d_state, e->lay, v_dev, mask_dev, e->n_envs);
   HIP_TRY(hipGetLastError());
   return COSIM_OK;
@@ -729,6 +903,8 @@ int cosim_debug_forward(cosim_engine_t* e, int env, const char* name, float* hos
   (void)name;
   HIP_TRY(hipSetDevice(e->device));
   int rc = upload_params(e);
+  if (rc) return rc;
+  rc = join_ranges(e, 0);
   if (rc) return rc;
   HIP_TRY(hipMemset(e->d_dbg, 0, 8192 * sizeof(float)));
   KArgs a = base_args(e);
@@ -747,6 +923,8 @@ int cosim_profile_step(cosim_engine_t* e, const float* actions_dev, const float*
   if (!e->launch_prof) return fail(COSIM_EINVAL, "cosim_profile_step: no diagnostic kernel for this model");
   HIP_TRY(hipSetDevice(e->device));
   int rc = upload_params(e);
+  if (rc) return rc;
+  rc = join_ranges(e, 0);
   if (rc) return rc;
   HIP_TRY(hipMemset(e->d_dbg, 0, 8192 * sizeof(float)));
   KArgs a = base_args(e);

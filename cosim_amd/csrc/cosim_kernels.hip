@@ -66,6 +66,8 @@ struct KArgs {
   int pair_coop;          // robot-robot pairs with a hull: 1 = one at a time, wave-cooperative vertex scans; 0 = lane-parallel
   int pair_boxbox;        // box-box pairs: 1 = mjc_BoxBox (up to eight contacts), 0 = through MPR like the other convex pairs (one contact)
   int prio[4];            // wave priority by solver lag: expected Newton iterations per substep, then the three lag thresholds
+  int* ovf;               // [N] per-env flag "this control step needs the large-capacity kernel" (null: no such kernel; contacts that find no slot are left out and counted)
+  int env_count;          // envs of this launch (the fix-up kernel scans ovf[env_first .. env_first + env_count))
 };
 
 // ------------------------------------------------------------------------------------------------ wave helpers
@@ -554,19 +556,18 @@ struct KTraits {
 // ------------------------------------------------------------------------------------------------ the kernel
 // HF: heightfield ground; SC: robot-robot (self) collision pairs; PROF: diagnostic build with s_memtime phase stamps;
 // EPW: environments per wave (1: lane l of 64 plays object l; 2: two groups of 32 lanes, RPL rows per lane of the group)
-template <int NV, int NB, int RPL, bool HF, int GTM, bool SC, bool PROF = false, int EPW = 1, int MCT = 0>
-// waves per SIMD the register allocator is asked for = what the LDS footprint admits (160 KiB per CU, 4 SIMDs): asking for more makes
-// the compiler spill for nothing, asking for less wastes resident waves
-__global__ __launch_bounds__(64, (EPW == 2 ? 2 : (163840 / (int)sizeof(typename KTraits<NV, NB, RPL, HF, SC, EPW, MCT>::L) + 3) / 4 >= 4 ? 4
-                                  : (163840 / (int)sizeof(typename KTraits<NV, NB, RPL, HF, SC, EPW, MCT>::L) + 3) / 4)) void env_kernel(KArgs kernarg_block) {
-  // The argument block is read from the kernarg segment where it is used, not copied into ~70 scalar registers at entry (that
-  // copy spilled into vector-register lanes for the whole kernel and cost the solver's loops their scalar temporaries): `A` is the
-  // block in constant memory, and KARGS_FENCE() at the phase boundaries keeps the loads of a phase inside that phase.
-  typedef const KArgs __attribute__((address_space(4)))* KArgsP;
-  KArgsP kargs_p = (KArgsP)__builtin_amdgcn_kernarg_segment_ptr();
-  (void)kernarg_block;
+// The argument block is read from the kernarg segment where it is used, not copied into ~70 scalar registers at entry (that
+// copy spilled into vector-register lanes for the whole kernel and cost the solver's loops their scalar temporaries): `A` is the
+// block in constant memory, and KARGS_FENCE() at the phase boundaries keeps the loads of a phase inside that phase.
+typedef const KArgs __attribute__((address_space(4)))* KArgsP;
 #define A (*kargs_p)
-#define KARGS_FENCE() asm volatile("" : "+s"(kargs_p))
+// (not in the fix-up kernel: it runs rarely, at one wave per SIMD, and the fence inside its loop over flagged envs does not compile)
+#define KARGS_FENCE() do { if constexpr (!FIX) asm volatile("" : "+s"(kargs_p)); } while (0)
+// One control step of environment `env` by the calling wave (EPW = 2: by the calling half-wave).  FIX: this is the large-capacity
+// kernel redoing a step that the fleet's kernel gave up on (see env_fixup_kernel); otherwise, where the engine has such a kernel
+// (A.ovf != null), a step whose contacts do not fit this kernel's slots is abandoned before anything is written and flagged.
+template <int NV, int NB, int RPL, bool HF, int GTM, bool SC, bool PROF, int EPW, int MCT, bool FIX>
+__device__ __forceinline__ void env_body(KArgsP kargs_p, const int env, typename KTraits<NV, NB, RPL, HF, SC, EPW, MCT>::L (&SS)[EPW]) {
   static_assert(EPW == 1 || (EPW == 2 && !HF && !SC && NV <= 32 && NB <= 32), "two environments per wave: flat ground, no pairs");
   static_assert(MCT == 0 || EPW == 1, "contact-twist mode: one environment per wave");
   using KT = KTraits<NV, NB, RPL, HF, SC, EPW, MCT>;
@@ -581,13 +582,12 @@ __global__ __launch_bounds__(64, (EPW == 2 ? 2 : (163840 / (int)sizeof(typename 
   constexpr int MC = L::MC;
   constexpr int NGENMAX = L::NGEN;
   constexpr int EPL = (TRI + 63) / 64;
-  __shared__ L SS[EPW];
+  // the fix-up kernel only ever steps (a constant there: its loop over flagged envs then has no exit the compiler must treat as divergent)
+  const int kmode = FIX ? (int)MODE_STEP : A.mode;
   const int wlane = threadIdx.x;
   const int hb = EPW == 1 ? 0 : (wlane & 32);          // first lane of this lane's group
   const int lane = EPW == 1 ? wlane : (wlane & 31);     // role index inside the group
   L& S = SS[EPW == 1 ? 0 : (wlane >> 5)];
-  const int env = A.mode == MODE_DEBUG ? A.dbg_env : A.env_first + (int)blockIdx.x * EPW + (EPW == 1 ? 0 : (wlane >> 5));
-  if (env >= A.n_envs) return;
   typedef const DevModel __attribute__((address_space(4)))* DevModelP;   // the model never changes while a kernel runs: constant address space = invariant loads
   const auto& dm = *(DevModelP)(unsigned long long)A.dm;
   typedef const DevObs __attribute__((address_space(4)))* DevObsP;   // wrapper configuration: constant for the engine's lifetime
@@ -618,7 +618,7 @@ __global__ __launch_bounds__(64, (EPW == 2 ? 2 : (163840 / (int)sizeof(typename 
   const unsigned k0 = A.seed_lo, k1 = A.seed_hi, g0 = (unsigned)gid, g1 = (unsigned)(gid >> 32);
 
   bool do_reset = false;
-  if (A.mode == MODE_RESET) {
+  if (kmode == MODE_RESET) {
     do_reset = A.mask == nullptr || A.mask[env] != 0;
     if (!do_reset) return;
   }
@@ -649,21 +649,20 @@ __global__ __launch_bounds__(64, (EPW == 2 ? 2 : (163840 / (int)sizeof(typename 
   int st_newton = 0, st_ls = 0, st_build = 0, st_rows = 0;  // solver statistics of this control step
   int st_dropcon = 0, st_droplim = 0, st_maxcon = 0;          // capacity: contacts / limit rows left out, most contacts seen in one substep
 
-  if (A.mode != MODE_RESET) {
+  if (kmode != MODE_RESET) {
     // ---- state -> LDS
     if (lane < nq) S.qpos[lane] = rec[lay.s_qpos + lane];
     if (lane < NV) { S.qvel[lane] = rec[lay.s_qvel + lane]; S.qacc[lane] = rec[lay.s_warm + lane]; S.qact[lane] = 0.f; }
     WSYNC();
 
     // ---- control (once per control step): delay filter + PD, zero-order hold over the substeps
-    if (A.mode == MODE_STEP) {
+    if (kmode == MODE_STEP) {
       const bool delayed = (ob.action_delay_prob > u01(philox_first(k0, k1, step_count, 0u, g0, g1))) && has_prev;  // control_manager.py:15-23
       if (lane < nu) {
         const auto& R = dm.rec[lane];
         const float raw_action = A.actions[(size_t)env * nu + lane];
         S.act[lane] = raw_action;
-        float filt = delayed ? rec[lay.s_delay + lane] : raw_action;
-        rec[lay.s_delay + lane] = raw_action;
+        float filt = delayed ? rec[lay.s_delay + lane] : raw_action;   // (the delay line is rewritten with the state, at the end)
         float a = filt * R.a_scale, g = R.a_cgear;
         float q = S.qpos[R.a_qadr] * g, qd = S.qvel[R.a_dadr] * g;
         float kp = par[lay.p_kp + lane], kd = par[lay.p_kd + lane];
@@ -684,7 +683,7 @@ __global__ __launch_bounds__(64, (EPW == 2 ? 2 : (163840 / (int)sizeof(typename 
       WSYNC();
     }
 
-    const int nsub = A.mode == MODE_DEBUG ? 1 : (A.nsub_override > 0 ? A.nsub_override : dm.frame_skip);
+    const int nsub = kmode == MODE_DEBUG ? 1 : (A.nsub_override > 0 ? A.nsub_override : dm.frame_skip);
 #pragma nounroll
     for (int sub = 0; sub < nsub; sub++) {
       int ln = lane;
@@ -947,7 +946,7 @@ __global__ __launch_bounds__(64, (EPW == 2 ? 2 : (163840 / (int)sizeof(typename 
 #pragma unroll
         for (int q = 0; q < 6; q++) bias += cd[q] * f[q];
         S.qsm[ln] = -R.d_damping * qv - bias + S.qact[ln];
-        if (A.mode == MODE_DEBUG && A.dbg != nullptr) A.dbg[1140 + ln] = bias;
+        if (kmode == MODE_DEBUG && A.dbg != nullptr) A.dbg[1140 + ln] = bias;
       }
 
       // sensors of this forward pass (framequat, gyro, velocimeter on the IMU site); only the last substep's are read
@@ -1622,6 +1621,15 @@ __global__ __launch_bounds__(64, (EPW == 2 ? 2 : (163840 / (int)sizeof(typename 
           if (ncon > MC) ncon = MC;
           if (ne + 4 * ncon > NGENMAX) ncon = (NGENMAX - ne) / 4;
         }
+        if constexpr (!FIX && EPW == 1) {
+          // more contacts than this kernel has slots for, and the engine has a large-capacity kernel: give the step up (nothing of
+          // it has been written) and flag the env; env_fixup_kernel redoes it from the same state right after this launch
+          // (readfirstlane: heightfield kernels read the count from LDS, which the compiler must take for a per-lane value)
+          if (kmode == MODE_STEP && A.ovf != nullptr && __builtin_amdgcn_readfirstlane(ncon_all - ncon - npc) > 0) {
+            if (ln == 0) A.ovf[env] = 1;
+            return;
+          }
+        }
         st_dropcon += ncon_all - ncon - npc;
         st_maxcon = max(st_maxcon, ncon_all);
       }
@@ -2076,7 +2084,7 @@ __global__ __launch_bounds__(64, (EPW == 2 ? 2 : (163840 / (int)sizeof(typename 
 
       update_constraint();
       float gradnorm = sqrtf(gradnorm2);
-      if (A.mode == MODE_DEBUG && A.dbg != nullptr) {
+      if (kmode == MODE_DEBUG && A.dbg != nullptr) {
         // dump position/velocity-stage intermediates before the solve
         float* D = A.dbg;
         if (ln == 0) { D[0] = (float)(ncon + (CT ? npc : 0)); D[1] = (float)nefc; D[2] = (float)ne; D[3] = (float)nf; D[4] = (float)nl; D[5] = cost; D[6] = gradnorm; D[7] = (float)ngen; }
@@ -2317,7 +2325,7 @@ __global__ __launch_bounds__(64, (EPW == 2 ? 2 : (163840 / (int)sizeof(typename 
       }
       st_newton += niter;
       st_rows += nefc;
-      if (A.mode == MODE_DEBUG && A.dbg != nullptr) {
+      if (kmode == MODE_DEBUG && A.dbg != nullptr) {
         float* D = A.dbg;
         if (ln == 0) { D[8] = (float)niter; D[9] = cost; D[10] = gradnorm; }
         if (ln < NV) { D[1000 + ln] = qacc_l; D[1040 + ln] = S.qcon[ln]; }
@@ -2383,7 +2391,7 @@ __global__ __launch_bounds__(64, (EPW == 2 ? 2 : (163840 / (int)sizeof(typename 
         const float qa = chol_solve_lds<NV, L::LD, LW>(S.u.H, dinv, rhs, ln, hb);
         WSYNC();
         if (PROF) { __builtin_amdgcn_s_waitcnt(0); unsigned long long t_ = __builtin_amdgcn_s_memtime(); pacc[15] += t_ - pt0; }   // implicit solve done (advance follows)
-        if (A.mode != MODE_DEBUG) {
+        if (kmode != MODE_DEBUG) {
           if (ln < NV) S.qvel[ln] = qv + h * qa;
           WSYNC();
           if (ln > 0 && ln < nbody) {
@@ -2414,7 +2422,7 @@ __global__ __launch_bounds__(64, (EPW == 2 ? 2 : (163840 / (int)sizeof(typename 
       }
       STAMP(8);   // implicitfast + advance
     }  // substeps
-    if (A.mode == MODE_DEBUG) return;
+    if (kmode == MODE_DEBUG) return;
 
     // ---- mj_checkPos/Vel: non-finite state -> this env is reset (MuJoCo resets the data and warns)
     {
@@ -2431,7 +2439,7 @@ __global__ __launch_bounds__(64, (EPW == 2 ? 2 : (163840 / (int)sizeof(typename 
   // =============================================================== info / flags (_get_info, flamingo_light_v1.py:166-183)
   // Written from the state the step ended in, BEFORE an auto-reset touches it: on the step that ends an episode the reference's
   // info describes that last step (the returned state vector, as in gym-style auto-reset, is the first one of the next episode).
-  if (A.mode == MODE_STEP) {
+  if (kmode == MODE_STEP) {
     WSYNC();
     if (A.info != nullptr) {
       float* inf = A.info + (size_t)env * ob.info_dim;
@@ -2574,17 +2582,59 @@ __global__ __launch_bounds__(64, (EPW == 2 ? 2 : (163840 / (int)sizeof(typename 
   }
   if (lane < nq) rec[lay.s_qpos + lane] = S.qpos[lane];
   if (lane < NV) { rec[lay.s_qvel + lane] = S.qvel[lane]; rec[lay.s_warm + lane] = S.qacc[lane]; }
-  if (lane < nu) rec[lay.s_lastact + lane] = do_reset ? 0.f : S.act[lane];
+  if (lane < nu) {
+    rec[lay.s_lastact + lane] = do_reset ? 0.f : S.act[lane];
+    if (kmode == MODE_STEP) rec[lay.s_delay + lane] = S.act[lane];   // control_manager.py:22: the raw action is what the filter keeps (has_prev = 0 after a reset: never read)
+  }
   if (lane == 0) {
     meta[0] = sim_step; meta[1] = (int)(step_count + 1u); meta[2] = has_prev; meta[4] = nan_resets;
     meta[5] += st_newton; meta[6] += st_ls; meta[7] += st_build; meta[3] += st_rows;
     meta[8] += st_dropcon; meta[9] += st_droplim; meta[10] = max(meta[10], st_maxcon);
-    if (A.mode == MODE_STEP && (terminated || truncated)) meta[11] += 1;   // episodes ended (device-side count: survives graph replay)
+    if (kmode == MODE_STEP && (terminated || truncated)) meta[11] += 1;   // episodes ended (device-side count: survives graph replay)
+    if constexpr (FIX) { meta[12] += 1; A.ovf[env] = 0; }                  // control steps redone by the large-capacity kernel
   }
-#undef A
 #undef ob
 #undef lay
-#undef KARGS_FENCE
 }
+
+template <int NV, int NB, int RPL, bool HF, int GTM, bool SC, bool PROF = false, int EPW = 1, int MCT = 0>
+// waves per SIMD the register allocator is asked for = what the LDS footprint admits (160 KiB per CU, 4 SIMDs): asking for more makes
+// the compiler spill for nothing, asking for less wastes resident waves
+__global__ __launch_bounds__(64, (EPW == 2 ? 2 : (163840 / (int)sizeof(typename KTraits<NV, NB, RPL, HF, SC, EPW, MCT>::L) + 3) / 4 >= 4 ? 4
+                                  : (163840 / (int)sizeof(typename KTraits<NV, NB, RPL, HF, SC, EPW, MCT>::L) + 3) / 4)) void env_kernel(KArgs kernarg_block) {
+  KArgsP kargs_p = (KArgsP)__builtin_amdgcn_kernarg_segment_ptr();
+  (void)kernarg_block;
+  __shared__ typename KTraits<NV, NB, RPL, HF, SC, EPW, MCT>::L SS[EPW];
+  const int env = A.mode == MODE_DEBUG ? A.dbg_env : A.env_first + (int)blockIdx.x * EPW + (EPW == 1 ? 0 : ((int)threadIdx.x >> 5));
+  if (env >= A.n_envs) return;
+  env_body<NV, NB, RPL, HF, GTM, SC, PROF, EPW, MCT, false>(kargs_p, env, SS);
+}
+
+// The large-capacity kernel behind a fleet kernel whose contact slots can run out (flamingo_light_v1 on the plane: 14 dense
+// contacts in the fleet kernel, 40 = four per geom, the most the plane narrowphase can emit, here).  Launched right after the fleet
+// kernel on the same stream with one wave per 64 envs of the range: the wave reads its 64 flags (one coalesced load; almost always
+// all zero: the launch costs a few microseconds) and redoes the control step of each flagged env from the untouched pre-step state.
+// MuJoCo's arena keeps every contact (reference flamingo_light_v1.py:154, do_simulation); this keeps that true at any count.
+// Registers and LDS per wave are those of the fleet kernel (launch bounds: four waves per SIMD = 128 registers; 9.7 KB of LDS): a fix-up
+// wave then fits the slot a finished fleet wave leaves behind.  With the footprint the compiler would choose freely (247 registers) it
+// had to wait until three of the four waves of some SIMD -- other ranges' fleet waves, a whole kernel long -- had gone: 13.9 -> 12.6 M.
+template <int NV, int NB, int RPL, bool HF, int GTM, bool SC, int MCT>
+__global__ __launch_bounds__(64, 4) void env_fixup_kernel(KArgs kernarg_block) {
+  KArgsP kargs_p = (KArgsP)__builtin_amdgcn_kernarg_segment_ptr();
+  (void)kernarg_block;
+  __shared__ typename KTraits<NV, NB, RPL, HF, SC, 1, MCT>::L SS[1];
+  const int base = A.env_first + (int)blockIdx.x * 64, e = base + (int)threadIdx.x;
+  const int fl = (e < A.env_first + A.env_count && e < A.n_envs) ? A.ovf[e] : 0;
+  unsigned long long m = __ballot(fl != 0);
+#pragma nounroll
+  while (m) {   // wave-uniform
+    const int env = base + __builtin_ctzll(m);
+    m &= m - 1;
+    env_body<NV, NB, RPL, HF, GTM, SC, false, 1, MCT, true>(kargs_p, env, SS);
+    WSYNC();
+  }
+}
+#undef A
+#undef KARGS_FENCE
 
 }  // namespace cosim

@@ -91,6 +91,9 @@ def load_library():
     L.cosim_reset.argtypes = [vp, vp, vp, vp, vp]
     L.cosim_step.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp]
     L.cosim_step_range.argtypes = [vp, ci, ci, vp, vp, vp, vp, vp, vp, vp]
+    L.cosim_join.argtypes = [vp, vp]
+    L.cosim_range.argtypes = [vp, ci, ctypes.POINTER(ci), ctypes.POINTER(ci), ctypes.POINTER(vp)]
+    L.cosim_range_mark.argtypes = [vp, ci]
     L.cosim_get.argtypes = [vp, ctypes.c_char_p, vp, vp]
     L.cosim_set.argtypes = [vp, ctypes.c_char_p, vp, vp]
     L.cosim_event_push.argtypes = [vp, vp, vp, vp]
@@ -100,6 +103,7 @@ def load_library():
     L.cosim_profile_step.argtypes = [vp] * 7
     L.cosim_last_error.restype = ctypes.c_char_p
     for fn in ("cosim_create", "cosim_destroy", "cosim_query", "cosim_set_param", "cosim_reset", "cosim_step", "cosim_step_range", "cosim_get",
+               "cosim_join", "cosim_range", "cosim_range_mark",
                "cosim_set", "cosim_event_push", "cosim_debug_forward", "cosim_kernel_time", "cosim_set_timing",
                "cosim_profile_step", "cosim_model_sizeof", "cosim_obs_config_sizeof"):
         getattr(L, fn).restype = ci
@@ -112,6 +116,7 @@ def load_library():
 
 
 EXPORTS = ["cosim_create", "cosim_destroy", "cosim_query", "cosim_set_param", "cosim_reset", "cosim_step", "cosim_step_range", "cosim_get",
+           "cosim_join", "cosim_range", "cosim_range_mark",
            "cosim_set", "cosim_event_push", "cosim_debug_forward", "cosim_kernel_time", "cosim_set_timing",
            "cosim_profile_step", "cosim_mlp_forward", "cosim_lstm_cell", "cosim_fleet_stats", "cosim_last_error", "cosim_model_sizeof", "cosim_obs_config_sizeof"]
 
@@ -234,6 +239,18 @@ class Engine:
     def step_range(self, first, count, actions_ptr, commands_ptr, state_out_ptr, term_ptr, trunc_ptr, info_ptr, stream=None):
         self._check(self.L.cosim_step_range(self.h, int(first), int(count), actions_ptr, commands_ptr, state_out_ptr, term_ptr, trunc_ptr,
                                             info_ptr, stream))
+
+    def join(self, stream=None):
+        self._check(self.L.cosim_join(self.h, stream))
+
+    def range(self, i: int):
+        """(first env, env count, hipStream_t or None) of range ``i`` (``cosim_range``)."""
+        first, count, st = ctypes.c_int(), ctypes.c_int(), ctypes.c_void_p()
+        self._check(self.L.cosim_range(self.h, int(i), ctypes.byref(first), ctypes.byref(count), ctypes.byref(st)))
+        return first.value, count.value, st.value
+
+    def range_mark(self, i: int):
+        self._check(self.L.cosim_range_mark(self.h, int(i)))
 
     def get(self, name: str, out_ptr, stream=None):
         self._check(self.L.cosim_get(self.h, name.encode(), out_ptr, stream))

@@ -86,10 +86,14 @@ int cosim_query(const cosim_engine_t* e, const char* name);
  * per control step, 0 = frame_skip), "boxbox_mode" (1, default: box-box geom pairs through the mjc_BoxBox routine, up to eight contacts
  * per pair; 0: through MPR like the other convex pairs, one contact), "pair_mode" (1, default: robot-robot pairs with a hull one at
  * a time with wave-cooperative vertex scans; 0: lane-parallel), "contact_twist" (flat flamingo_light_v1 only; 1: ground contacts in
- * twist space, 32 slots instead of the dense-row kernel's 12, at ~70 % of the speed; before the first step), "ls_tolerance_scale"
- * (multiplies the line-search tolerance; 1 = the model's).
+ * twist space, 32 slots instead of the dense-row kernel's 14, at ~70 % of the speed; before the first step), "ls_tolerance_scale"
+ * (multiplies the line-search tolerance; 1 = the model's), "ranges" (1..16: cosim_step issues the fleet as that many launches over
+ * contiguous env ranges on engine-owned streams; default 1), "deferred_join" (see cosim_step / cosim_join), "inflight" (control steps cosim_step lets the host run ahead of each
+ * range stream before it blocks, default 4, 0 = unbounded: deep queues step slower on this runtime), "fixup" (0 switches the
+ * large-capacity fix-up launches off: contacts beyond the fleet kernel's slots are then left out and counted).
  * cosim_query additionally answers "contact_slots" / "pair_slots" (capacity of the selected kernel variant: heightfields with cells
- * of 10 cm or more select the 48-slot variants of flamingo_light_v1 / w4_p_v2) and "lds_bytes". */
+ * of 10 cm or more select the 48-slot variants of flamingo_light_v1 / w4_p_v2), "fixup_contact_slots" (capacity of the kernel that
+ * redoes a control step whose contacts did not fit; 0: this model / terrain has none), "ranges" and "lds_bytes". */
 int cosim_set_param(cosim_engine_t* e, const char* name, const float* host, int count);
 
 /* Replaces env.reset() (reference envs/wrappers.py:245-256,303-307,385-389; flamingo_light_v1.py:209-232).
@@ -105,6 +109,18 @@ int cosim_reset(cosim_engine_t* e, const uint8_t* mask_dev, const float* command
  * [action_diff_RMSE, lin_vel_x, lin_vel_y, ang_vel_yaw, torque[nu], set_points[nu], state[k]]. */
 int cosim_step(cosim_engine_t* e, const float* actions_dev, const float* commands_dev, float* state_out_dev,
                uint8_t* terminated_dev, uint8_t* truncated_dev, float* info_out_dev, void* stream);
+/* With "ranges" > 1, cosim_step forks: the engine's range streams wait for `stream` (the step's inputs), each steps its range, and
+ * `stream` then waits for all of them (join) -- unless "deferred_join" is 1: the join is then left to cosim_join, or to the next
+ * cosim_reset / cosim_get / cosim_set / cosim_event_push (they join first).  A deferred join is what lets a range's next control
+ * step start while the other ranges are still inside the current one (a launch ends with its slowest env): a caller whose next
+ * actions do not depend on the whole fleet's last outputs (an action table, or a policy evaluated per range on the range's stream:
+ * cosim_range) calls cosim_step back to back and joins when it reads results.  (The reference steps one env: core/tester.py:90.) */
+int cosim_join(cosim_engine_t* e, void* stream);
+/* Range i of "ranges": its first env, env count and stream (hipStream_t; NULL when ranges == 1).  Work enqueued on that stream from
+ * outside (a per-range policy, a reporter reduction) is ordered with the range's steps; cosim_range_mark(i) re-arms the range's
+ * "done" event afterwards so that the next join waits for that work too. */
+int cosim_range(const cosim_engine_t* e, int i, int* first, int* count, void** stream);
+int cosim_range_mark(cosim_engine_t* e, int i);
 
 /* The same control step for envs [first, first + count) only; every pointer still addresses the WHOLE fleet's buffers ([N, ...]).
  * Lets a caller step one fleet as several independent shards on streams of its own (a shard's next control step fills the tail

@@ -223,33 +223,106 @@ def test_observation_pipeline_matches_wrapper_restatement(parity):
 
 
 def test_action_delay_follows_host_philox_stream(parity):
+    """A3 on the device, EVERY step (reference manager/control_manager.py:14-23): with action_delay_prob = 0.5 the shoulder torque
+    of step t must be kp (s filt[t] - q) - kd qd with filt = the reference's delay filter driven by the host twin of the device's
+    Philox draws, q / qd read back before the step.  Shoulders are position-PD and, at this amplitude, far from the +-17 clamp, so
+    the torque is an affine function of the filtered action: a kernel that never delays, always delays, delays by the previous
+    FILTERED action, or keeps has_prev wrong fails on the first delayed step."""
     from cosim_amd import rng as crng
     from cosim_amd.config import PARITY_RANDOM, make_config
     from cosim_amd.compile import compile_model
     from cosim_amd.batched_env import BatchedEnv
+    from cosim_amd.model import get_field
     from oracle.envlayer import delay_filter_sequence
     torch = parity["torch"]
     rnd = dict(PARITY_RANDOM, action_delay_prob=0.5)
     cfg = make_config("flamingo_light_v1", random=rnd)
-    n, T, seed, id0 = 16, 12, 1234, 100
-    env = BatchedEnv(cfg, num_envs=n, auto_reset=False, seed=seed, env_id0=id0, compiled=compile_model(cfg))
+    n, T, seed, id0 = 16, 24, 1234, 100
+    cm = compile_model(cfg)
+    env = BatchedEnv(cfg, num_envs=n, auto_reset=False, seed=seed, env_id0=id0, compiled=cm)
     env.reset()
-    acts = np.random.default_rng(0).uniform(-1, 1, size=(T, n, 4)).astype(np.float32)
-    tq = []
-    for t in range(T):
-        _, _, _, info = env.step(torch.tensor(acts[t], device=env.device))
-        tq.append(info["torque"][:, 2].cpu().numpy().copy())       # left wheel: tq = kd (40 a_filtered - qd), |.| <= 17
+    scale = np.array(get_field(cm.blob, "ctl_scale")[:4])
+    acts = np.random.default_rng(0).uniform(-0.3, 0.3, size=(T, n, 4)).astype(np.float32)
     # the reset consumed step counter 0, so control step t uses counter t + 1
     u = np.stack([crng.uniform(seed, np.arange(id0, id0 + n), t + 1, crng.PURPOSE_DELAY, 0) for t in range(T)])
-    delayed_any = 0
-    for e in range(n):
-        filt = delay_filter_sequence(acts[:, e, :], u[:, e], 0.5)
-        delayed_any += int((filt != acts[:, e, :]).any())
-        # wheel torque saturates often; check the sign pattern and the unsaturated values of the first step exactly
-        exp0 = np.clip(0.3 * (40 * filt[0, 2] - 0.0), -17, 17)
-        assert tq[0][e] == pytest.approx(exp0, abs=1e-4)
-    assert delayed_any > n // 2
+    filt = np.stack([delay_filter_sequence(acts[:, e, :], u[:, e], 0.5) for e in range(n)], axis=1)      # [T, n, 4]
+    assert (filt[0] == acts[0]).all()                         # the first step after a reset is never delayed (no previous action)
+    delayed = (filt != acts).any(axis=2)                      # [T, n]
+    assert delayed[1:].sum() > T * n // 4 and (~delayed[1:]).sum() > T * n // 4
+    sh_q, sh_d = [7, 10], [6, 9]                              # shoulder qpos / dof addresses (SURVEY App. A)
+    worst, margin = 0.0, []
+    for t in range(T):
+        d = env.get_data()
+        q, qd = d.qpos.cpu().numpy().astype(np.float64), d.qvel.cpu().numpy().astype(np.float64)
+        _, _, _, info = env.step(torch.tensor(acts[t], device=env.device))
+        tq = info["torque"][:, 0:2].cpu().numpy().astype(np.float64)
+        exp = env.kp[:, 0:2] * (scale[0:2] * filt[t][:, 0:2] - q[:, sh_q]) - env.kd[:, 0:2] * qd[:, sh_d]
+        alt = env.kp[:, 0:2] * (scale[0:2] * acts[t][:, 0:2] - q[:, sh_q]) - env.kd[:, 0:2] * qd[:, sh_d]   # what "no delay" would give
+        assert np.abs(exp).max() < 16.0                        # unsaturated: the comparison sees the filtered action itself
+        worst = max(worst, float(np.abs(tq - exp).max()))
+        np.testing.assert_allclose(tq, exp, atol=2e-4, err_msg=f"step {t}")
+        margin.append(np.abs(exp - alt)[delayed[t]])
+    margin = np.concatenate([m.ravel() for m in margin])
+    assert np.median(margin) > 100 * 2e-4                      # on delayed steps the undelayed law is far outside the tolerance
     env.close()
+
+
+def test_more_contacts_than_the_fleet_kernel_holds_are_redone_not_dropped(parity):
+    """MuJoCo's arena keeps every contact (reference flamingo_light_v1.py:154).  The fleet kernel of flamingo_light_v1 on the plane
+    has 14 dense contact slots; a robot placed in an arbitrary pose on the ground makes up to ~34 contacts in its first control
+    steps.  Such a control step is given up by the fleet kernel and redone by the 40-slot kernel launched right behind it: nothing is
+    left out (dropped_contacts == 0), the redone steps are counted, and the results follow the oracle like any other replay; with
+    the fix-up switched off the same batch does leave contacts out and lands far from the oracle."""
+    from oracle.oracle import Oracle
+    torch = parity["torch"]
+    o = Oracle(parity["cm"])
+    rng = np.random.default_rng(3)
+    R = dict(qpos=[], qvel=[], warm=[], act=[], qpos1=[], qvel1=[], ncon=[])
+    for trial in range(200):
+        q = parity["q0"].copy()
+        quat = rng.normal(size=4)
+        q[2] = rng.uniform(0.05, 0.25)
+        q[3:7] = quat / np.linalg.norm(quat)
+        q[7:] += rng.uniform(-0.3, 0.3, size=q.size - 7)
+        o.reset(q)
+        for t in range(2):
+            a = 0.3 * np.sin(0.3 * t + np.arange(4))
+            R["qpos"].append(o.qpos.copy()); R["qvel"].append(o.qvel.copy()); R["warm"].append(o.qacc_warmstart.copy()); R["act"].append(a)
+            o.control_step(a)
+            R["qpos1"].append(o.qpos.copy()); R["qvel1"].append(o.qvel.copy()); R["ncon"].append(o.ncon)
+    R = {k: np.array(v) for k, v in R.items()}
+    big = R["ncon"] > 14                      # (contacts of the step's last substep: the count changes inside the step)
+    assert big.sum() >= 40 and R["ncon"].max() >= 30, (big.sum(), R["ncon"].max())
+    n = len(R["ncon"])
+
+    def run(fixup):
+        env = _env(parity, n)
+        assert env.engine.query("contact_slots") == 14 and env.engine.query("fixup_contact_slots") == 40
+        if not fixup:
+            env.engine.set_param("fixup", np.array([0.0]))
+        env.reset()
+        env.set_state(R["qpos"], R["qvel"], R["warm"])
+        env.step(torch.tensor(R["act"], dtype=torch.float32, device=env.device))
+        d = env.get_data()
+        qp, qv = d.qpos.cpu().numpy().astype(np.float64), d.qvel.cpu().numpy().astype(np.float64)
+        st = env.solver_stats()
+        env.close()
+        return qp, qv, st
+
+    qp, qv, st = run(True)
+    assert st["dropped_contacts"] == 0 and st["nan_resets"] == 0 and 30 <= st["max_contacts"] <= 40
+    assert big.sum() <= st["fixup_steps"] <= 3 * big.sum(), (st["fixup_steps"], big.sum())
+    ev = np.abs(qv - R["qvel1"]).max(axis=1)
+    assert np.abs(qp - R["qpos1"]).max() < 2e-5
+    assert ev.max() < 2e-3 and np.median(ev) < 2e-4, (ev.max(), np.median(ev))      # measured: max 6.6e-4, median 2e-5 (rad/s, m/s)
+    qp0, qv0, st0 = run(False)
+    assert st0["dropped_contacts"] > 0 and st0["fixup_steps"] == 0
+    ev0 = np.abs(qv0 - R["qvel1"]).max(axis=1)
+    assert np.median(ev0[big]) > 20 * np.median(ev[big]) and ev0.max() > 1.0, (np.median(ev0[big]), np.median(ev[big]), ev0.max())
+    same = R["ncon"] < 8
+    assert same.sum() > 50
+    untouched = (qv0[same] == qv[same]).all(axis=1)
+    assert untouched.mean() > 0.9                                # envs within the slots take the fleet kernel either way: same bits
 
 
 def test_shard_invariance_and_auto_reset(parity):
