@@ -45,6 +45,34 @@ def _cmd_slices(stacked, non_stacked, dims, stack_size, command_dim):
     return out
 
 
+def draw_env_params(config: dict, cm: CompiledModel, seed: int, gids, gain_noise: float = 0.0) -> Dict[str, np.ndarray]:
+    """Per-env domain randomisation as pure functions of (seed, global env id): body masses (XMLManager step 3, reference
+    manager/xml_manager.py:43-55: ``mass += U(-m k, +m k)`` on the listed bodies, ``+ load`` on the base) and PD gains
+    (table value x U(1 - g, 1 + g)).  Shared by ``BatchedEnv`` and by the CPU twin of a fleet env (oracle/fleet.py)."""
+    blob = cm.blob
+    gids = np.asarray(gids, dtype=np.uint64)
+    N, nb, nu = len(gids), blob.nbody, blob.nu
+    mass = np.tile(np.array(get_field(blob, "body_mass")[:nb]), (N, 1))
+    k, load = config["random"]["mass_noise"], config["random"]["load"]
+    robot = ROBOTS[config["env"]["id"]]
+    for name in robot["mass_bodies"]:
+        b = cm.body_names.index(name)
+        m0 = mass[:, b].copy()
+        u = crng.uniform(seed, gids, 0, crng.PURPOSE_MASS, b).astype(np.float64)
+        mass[:, b] = m0 + (2.0 * u - 1.0) * m0 * k
+        if name == robot["base_body"]:
+            mass[:, b] += load
+    kp = np.tile(np.array(get_field(blob, "ctl_kp")[:nu]), (N, 1))
+    kd = np.tile(np.array(get_field(blob, "ctl_kd")[:nu]), (N, 1))
+    if gain_noise > 0:
+        idx = np.arange(nu)[None, :]
+        up = crng.uniform(seed, gids[:, None], 0, crng.PURPOSE_GAIN, idx)
+        ud = crng.uniform(seed, gids[:, None], 1, crng.PURPOSE_GAIN, idx)
+        kp = kp * (1.0 + gain_noise * (2.0 * up - 1.0))
+        kd = kd * (1.0 + gain_noise * (2.0 * ud - 1.0))
+    return {"body_mass": mass, "kp": kp, "kd": kd}
+
+
 class _Data:
     """What ``get_data()`` hands out: batched ``qpos`` / ``qvel`` views (reference: the MjData object)."""
 
@@ -158,35 +186,15 @@ class BatchedEnv:
 
     # ------------------------------------------------------------------ domain randomisation (XMLManager step 3)
     def _randomise(self, gain_noise: float):
-        cfg, blob, cm = self.config, self.cm.blob, self.cm
-        N, nb = self.num_envs, blob.nbody
-        gids = np.arange(self.env_id0, self.env_id0 + N, dtype=np.uint64)
-        mass = np.tile(np.array(get_field(blob, "body_mass")[:nb]), (N, 1))
-        k, load = cfg["random"]["mass_noise"], cfg["random"]["load"]
-        robot = ROBOTS[self.id]
-        for name in robot["mass_bodies"]:
-            b = cm.body_names.index(name)
-            m0 = mass[:, b].copy()
-            u = crng.uniform(self.seed, gids, 0, crng.PURPOSE_MASS, b).astype(np.float64)
-            mass[:, b] = m0 + (2.0 * u - 1.0) * m0 * k
-            if name == robot["base_body"]:
-                mass[:, b] += load
-        self.body_mass = mass
-        c = env_constants(cm, mass)
-        self.engine.set_param("body_mass", mass)
+        gids = np.arange(self.env_id0, self.env_id0 + self.num_envs, dtype=np.uint64)
+        p = draw_env_params(self.config, self.cm, self.seed, gids, gain_noise)
+        self.body_mass, self.kp, self.kd = p["body_mass"], p["kp"], p["kd"]
+        c = env_constants(self.cm, self.body_mass)
+        self.engine.set_param("body_mass", self.body_mass)
         self.engine.set_param("body_invweight0", c["body_invweight0"][:, :, 0])
         self.engine.set_param("dof_invweight0", c["dof_invweight0"])
         self.engine.set_param("meaninertia", c["meaninertia"])
-        nu = blob.nu
-        self.kp = np.tile(np.array(get_field(blob, "ctl_kp")[:nu]), (N, 1))
-        self.kd = np.tile(np.array(get_field(blob, "ctl_kd")[:nu]), (N, 1))
         if gain_noise > 0:
-            kp, kd = self.kp, self.kd
-            idx = np.arange(nu)[None, :]
-            up = crng.uniform(self.seed, gids[:, None], 0, crng.PURPOSE_GAIN, idx)
-            ud = crng.uniform(self.seed, gids[:, None], 1, crng.PURPOSE_GAIN, idx)
-            self.kp = kp * (1.0 + gain_noise * (2.0 * up - 1.0))
-            self.kd = kd * (1.0 + gain_noise * (2.0 * ud - 1.0))
             self.engine.set_param("kp", self.kp)
             self.engine.set_param("kd", self.kd)
 
@@ -316,7 +324,9 @@ class BatchedEnv:
                 "ls_evals": int(m[6]), "factorisations": int(m[7]), "dropped_contacts": int(m[8]), "dropped_limit_rows": int(m[9]),
                 "max_contacts": int(mi[:, 10].max().item()), "episodes_ended": int(m[11]),
                 # control steps redone by the large-capacity kernel because their contacts did not fit the fleet kernel's slots
-                "fixup_steps": int(m[12])}
+                "fixup_steps": int(m[12]),
+                # heightfield: geoms whose prism walk hit the 32768-prism bound (counted in dropped_contacts too)
+                "truncated_walks": int(m[13])}
 
     def render(self):
         pass  # headless

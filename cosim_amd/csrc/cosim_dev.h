@@ -94,7 +94,7 @@ struct Layout {
   // meta words (int bits): [0] sim_step [1] step_count [2] has_prev [3] sum nefc [4] nan_resets [5] Newton iterations
   // [6] line-search evaluations [7] Hessian factorisations (cumulative since creation; [3] per substep) [8] contacts left out for
   // lack of slots / rows [9] limit rows left out [10] most contacts detected in one substep [11] episodes ended
-  // [12] control steps redone by the large-capacity kernel (env_fixup_kernel)
+  // [12] control steps redone by the large-capacity kernel (env_fixup_kernel) [13] heightfield prism walks cut short (also in [8])
   static constexpr int NMETA = 16;
   // parameter record
   int p_mass, p_binvw, p_dinvw, p_floss, p_gmu, p_kp, p_kd, p_mean, p_stride;

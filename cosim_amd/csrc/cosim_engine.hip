@@ -434,10 +434,13 @@ int cosim_mlp_forward(const float* x_dev, int n, int n_layers, const int* dims, 
   }
   a.x = x_dev; a.out = out_dev; a.nl = n_layers; a.n = n; a.clip = clip; a.ld = maxd | 1;
   const size_t lds = (size_t)2 * 32 * a.ld * sizeof(float);
-  static size_t lds_allowed = 0;
-  if (lds > lds_allowed) {
+  static size_t lds_allowed[64] = {0};   // per device: the attribute belongs to the function on the device it was set on
+  int dev = 0;
+  HIP_TRY(hipGetDevice(&dev));
+  if (dev < 0 || dev >= 64) return fail(COSIM_EINVAL, "cosim_mlp_forward: device index out of range");
+  if (lds > lds_allowed[dev]) {
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_forward_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    lds_allowed = lds;
+    lds_allowed[dev] = lds;
   }
   hipLaunchKernelGGL(mlp_forward_kernel, dim3((n + 31) / 32), dim3(256), lds, (hipStream_t)stream, a);
   HIP_TRY(hipGetLastError());
@@ -452,10 +455,13 @@ int cosim_lstm_cell(const float* x_dev, const float* h_dev, const float* c_dev, 
   a.x = x_dev; a.h = h_dev; a.c = c_dev; a.W = w_dev; a.R = r_dev; a.B = b_dev; a.h_out = h_out_dev; a.c_out = c_out_dev;
   a.n = n; a.I = in_dim; a.H = hidden; a.ld = (in_dim + hidden) | 1;
   const size_t lds = (size_t)32 * a.ld * sizeof(float);
-  static size_t lds_allowed = 0;
-  if (lds > lds_allowed) {
+  static size_t lds_allowed[64] = {0};   // per device
+  int dev = 0;
+  HIP_TRY(hipGetDevice(&dev));
+  if (dev < 0 || dev >= 64) return fail(COSIM_EINVAL, "cosim_lstm_cell: device index out of range");
+  if (lds > lds_allowed[dev]) {
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_cell_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    lds_allowed = lds;
+    lds_allowed[dev] = lds;
   }
   hipLaunchKernelGGL(lstm_cell_kernel, dim3((n + 31) / 32), dim3(256), lds, (hipStream_t)stream, a);
   HIP_TRY(hipGetLastError());

@@ -648,6 +648,7 @@ __device__ __forceinline__ void env_body(KArgsP kargs_p, const int env, typename
   int terminated = 0, truncated = 0, bad = 0;
   int st_newton = 0, st_ls = 0, st_build = 0, st_rows = 0;  // solver statistics of this control step
   int st_dropcon = 0, st_droplim = 0, st_maxcon = 0;          // capacity: contacts / limit rows left out, most contacts seen in one substep
+  int st_walkcut = 0;                                         // heightfield: geoms whose prism walk was cut short (bounded walk)
 
   if (kmode != MODE_RESET) {
     // ---- state -> LDS
@@ -1075,7 +1076,7 @@ __device__ __forceinline__ void env_body(KArgsP kargs_p, const int env, typename
             if (ln == 0) S.ncon_ctr = 0;
             PEXT_T0();
             int n_items = 0;
-            bool coop_geom = false;
+            bool coop_geom = false, walk_cut = false;
             if (active) {
               // phase A (lane = geom): MuJoCo's early outs, then the sub-grid under the geom's axis-aligned box
               CObj og;
@@ -1122,7 +1123,7 @@ __device__ __forceinline__ void env_body(KArgsP kargs_p, const int env, typename
                   int rmin = (int)floor((y0 + T.sy) / T.dy), rmax = (int)ceil((y1 + T.sy) / T.dy);
                   cmin = max(cmin, 0); rmin = max(rmin, 0); cmax = min(cmax, T.ncol - 1); rmax = min(rmax, T.nrow - 1);
                   const int ppr = 2 * (cmax - cmin + 1) - 2;   // prisms per strip row: consecutive vertex triples of 2 ncols strip vertices
-                  if (ppr > 0 && (rmax - rmin) * ppr > 32768) { rmax = rmin + 32768 / ppr; st_dropcon++; }   // bounded walk (a 0.6 m x 0.6 m footprint of 1 cm cells fits); counted
+                  if (ppr > 0 && (rmax - rmin) * ppr > 32768) { rmax = rmin + 32768 / ppr; walk_cut = true; }   // bounded walk (a 0.6 m x 0.6 m footprint of 1 cm cells fits); counted below
                   if (rmax > rmin && ppr > 0) {
                     n_items = (rmax - rmin) * ppr;
                     S.hf_cmin[ln] = cmin; S.hf_rmin[ln] = rmin; S.hf_ppr[ln] = ppr; S.hf_lo[ln] = lo[2]; S.hf_mg[ln] = margin;
@@ -1133,6 +1134,7 @@ __device__ __forceinline__ void env_body(KArgsP kargs_p, const int env, typename
                 }
               }
             }
+            st_walkcut += __popcll(__ballot(walk_cut));   // wave-uniform (lane 0 writes the counters back): one per geom whose walk was cut short
             int end = n_items;   // inclusive prefix sum over the geom lanes
 #pragma unroll
             for (int o = 1; o < 32; o <<= 1) { const int t = __shfl_up(end, o, 64); if (ln >= o) end += t; }
@@ -2589,7 +2591,7 @@ __device__ __forceinline__ void env_body(KArgsP kargs_p, const int env, typename
   if (lane == 0) {
     meta[0] = sim_step; meta[1] = (int)(step_count + 1u); meta[2] = has_prev; meta[4] = nan_resets;
     meta[5] += st_newton; meta[6] += st_ls; meta[7] += st_build; meta[3] += st_rows;
-    meta[8] += st_dropcon; meta[9] += st_droplim; meta[10] = max(meta[10], st_maxcon);
+    meta[8] += st_dropcon + st_walkcut; meta[9] += st_droplim; meta[10] = max(meta[10], st_maxcon); meta[13] += st_walkcut;
     if (kmode == MODE_STEP && (terminated || truncated)) meta[11] += 1;   // episodes ended (device-side count: survives graph replay)
     if constexpr (FIX) { meta[12] += 1; A.ovf[env] = 0; }                  // control steps redone by the large-capacity kernel
   }

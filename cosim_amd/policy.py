@@ -283,6 +283,8 @@ def _lstm_cell_hip(self, x, h, c, W, R, Bv):
     hn, cn = t.empty_like(h), t.empty_like(c)
     rc = self._lstm_lib.cosim_lstm_cell(x.data_ptr(), h.data_ptr(), c.data_ptr(), x.shape[0], x.shape[1], h.shape[1], W.data_ptr(), R.data_ptr(),
                                         Bv.data_ptr(), hn.data_ptr(), cn.data_ptr(), t.cuda.current_stream(x.device).cuda_stream)
+    if rc == -1:      # COSIM_EINVAL: a shape the fused cell does not take (in_dim + hidden > 1200): the interpreter's own ops run
+        return None
     if rc != 0:
         raise RuntimeError(self._lstm_lib.cosim_last_error().decode())
     return hn, cn
@@ -405,9 +407,11 @@ class LSTMPolicy:
         if mask is None:
             self.h_in.zero_(); self.c_in.zero_()
         else:
-            keep = (self.torch.as_tensor(mask, device=self.device) == 0).to(self.h_in.dtype)[None, :, None]
-            self.h_in.mul_(keep)
-            self.c_in.mul_(keep)
+            # masked_fill, not a multiply by a 0 / 1 mask: NaN * 0 is NaN, and a non-finite recurrent state must not survive the
+            # reset of its env (it would emit NaN actions and be NaN-reset every step from then on)
+            done = (self.torch.as_tensor(mask, device=self.device) != 0)[None, :, None]
+            self.h_in.masked_fill_(done, 0.0)
+            self.c_in.masked_fill_(done, 0.0)
 
     def get_action(self, state):
         t = self.torch

@@ -106,6 +106,9 @@ class Runner:
         if self.reporter is not None and getattr(self.reporter, "trace_env", None) is not None:
             raise ValueError("test_graphed: a reporter with trace_env reads the device every step; use Runner.test")
         state, _ = env.reset()
+        # the device-side episode counter is cumulative since the engine was created (earlier runs on a reused env included): this
+        # run reports the difference, like the eager loop, which counts per run
+        episodes0 = env.solver_stats()["episodes_ended"]
         env.receive_user_command(self.user_command)
         action = t.zeros((env.num_envs, env.action_dim), dtype=t.float32, device=env.device)
 
@@ -136,5 +139,5 @@ class Runner:
         if self.reporter is not None and hasattr(self.reporter, "steps"):
             self.reporter.steps = steps          # write_info ran once per replay on the device, once in Python
         if self.reporter is not None and hasattr(self.reporter, "episodes_ended"):
-            self.reporter.episodes_ended = env.solver_stats()["episodes_ended"]   # counted on the device (meta[11]), graph or not
+            self.reporter.episodes_ended = env.solver_stats()["episodes_ended"] - episodes0   # counted on the device (meta[11]), graph or not
         return steps

@@ -1711,10 +1711,31 @@ void oracle_contact(oracle_data* d, int i, double* out) {
 }
 
 /* nsteps control steps in one call (actions[nsteps][nu], already delay-filtered): the timing loop of bench.py's CPU leg */
+void oracle_control_step(oracle_data* d, const double* filtered_action, double* tq);
 int oracle_rollout(oracle_data* d, const double* actions, int nsteps) {
   double tq[CS_MAXU];
   int t;
   for (t = 0; t < nsteps && !d->bad; t++) oracle_control_step(d, actions + (size_t)t * d->m.nu, tq);
+  return t;
+}
+
+/* The same loop with the robot env's `_is_done` (reference flamingo_p_v3.py:225-233: any signed component of cfrc_ext of the listed
+   bodies above 1.0; the other robots never terminate): stops after the control step that terminates.  Returns the steps done. */
+int oracle_rollout_env(oracle_data* d, const double* actions, int nsteps, int* terminated) {
+  double tq[CS_MAXU];
+  const cosim_model_t* m = &d->m;
+  int t = 0;
+  *terminated = 0;
+  while (t < nsteps && !d->bad) {
+    oracle_control_step(d, actions + (size_t)t * m->nu, tq);
+    t++;
+    if (m->term_mode == 1) {
+      for (int i = 0; i < m->nterm_body; i++)
+        for (int k = 0; k < 6; k++)
+          if (d->cfrc_ext[m->term_body[i]][k] > 1.0) *terminated = 1;
+      if (*terminated) break;
+    }
+  }
   return t;
 }
 

@@ -49,6 +49,7 @@ def lib():
         L.oracle_contact.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
         L.oracle_control_step.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
         L.oracle_rollout.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
+        L.oracle_rollout_env.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_int)]
         L.oracle_mpr_pair.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
         L.oracle_mpr_prims.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
                                        ctypes.c_void_p]
@@ -182,6 +183,15 @@ class Oracle:
         a = np.ascontiguousarray(actions, dtype=np.float64)
         assert a.ndim == 2 and a.shape[1] == self.cm.blob.nu
         return int(self.L.oracle_rollout(self.h, a.ctypes.data, a.shape[0]))
+
+    def rollout_env(self, actions: np.ndarray):
+        """Like ``rollout`` but with the robot env's ``_is_done``: stops after the control step that terminates (flamingo_p_v3's
+        cfrc_ext rule) or on a bad state.  Returns (steps done, terminated)."""
+        a = np.ascontiguousarray(actions, dtype=np.float64)
+        assert a.ndim == 2 and a.shape[1] == self.cm.blob.nu
+        term = ctypes.c_int(0)
+        n = int(self.L.oracle_rollout_env(self.h, a.ctypes.data, a.shape[0], ctypes.byref(term)))
+        return n, bool(term.value)
 
     def ray_down(self, x: float, y: float, z0: float) -> float:
         return self.L.oracle_ray_down(self.h, x, y, z0)

