@@ -2599,11 +2599,15 @@ __device__ __forceinline__ void env_body(KArgsP kargs_p, const int env, typename
 #undef lay
 }
 
+// waves per CU that LDS admits -> waves per SIMD to ask the register allocator for.  13 waves per CU are 4 + 3 + 3 + 3: asking for
+// 4 everywhere (128 registers) made the flamingo_light_v1 coarse-heightfield kernel spill 169 registers for one extra wave on one
+// SIMD (4.4 -> 3.7 M env-steps/s on light_rocky); 9 and 10 keep asking for 3 (the fine-cell kernels were tuned there)
+constexpr int waves_per_simd(int per_cu) { return per_cu >= 15 ? 4 : per_cu >= 9 ? 3 : per_cu >= 5 ? 2 : 1; }
+
 template <int NV, int NB, int RPL, bool HF, int GTM, bool SC, bool PROF = false, int EPW = 1, int MCT = 0>
 // waves per SIMD the register allocator is asked for = what the LDS footprint admits (160 KiB per CU, 4 SIMDs): asking for more makes
 // the compiler spill for nothing, asking for less wastes resident waves
-__global__ __launch_bounds__(64, (EPW == 2 ? 2 : (163840 / (int)sizeof(typename KTraits<NV, NB, RPL, HF, SC, EPW, MCT>::L) + 3) / 4 >= 4 ? 4
-                                  : (163840 / (int)sizeof(typename KTraits<NV, NB, RPL, HF, SC, EPW, MCT>::L) + 3) / 4)) void env_kernel(KArgs kernarg_block) {
+__global__ __launch_bounds__(64, (EPW == 2 ? 2 : waves_per_simd(163840 / (int)sizeof(typename KTraits<NV, NB, RPL, HF, SC, EPW, MCT>::L)))) void env_kernel(KArgs kernarg_block) {
   KArgsP kargs_p = (KArgsP)__builtin_amdgcn_kernarg_segment_ptr();
   (void)kernarg_block;
   __shared__ typename KTraits<NV, NB, RPL, HF, SC, EPW, MCT>::L SS[EPW];
