@@ -479,6 +479,18 @@ int cosim_fleet_stats(const float* info_dev, int n, int info_dim, int nu, const 
   return COSIM_OK;
 }
 
+int cosim_fleet_hist(const float* info_dev, int n, int info_dim, int nu, const float* cmd_dev, int cmd_stride, int ncmd, const float* hi_dev,
+                     int nbins, double* hist_dev, void* stream) {
+  if (!info_dev || !hi_dev || !hist_dev || n <= 0 || nu < 0 || ncmd < 0 || ncmd > 3 || 4 + nu + ncmd > 32 || info_dim < 4 + nu || nbins < 2 ||
+      (ncmd > 0 && !cmd_dev))
+    return fail(COSIM_EINVAL, "cosim_fleet_hist: bad argument");
+  const int blocks = n >= 8 * 64 ? 64 : (n + 7) / 8;
+  hipLaunchKernelGGL(fleet_hist_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, info_dev, n, info_dim, nu, cmd_dev, cmd_stride, ncmd,
+                     hi_dev, nbins, hist_dev);
+  HIP_TRY(hipGetLastError());
+  return COSIM_OK;
+}
+
 const char* cosim_last_error(void) { return g_err.c_str(); }
 int cosim_model_sizeof(void) { return (int)sizeof(cosim_model_t); }
 int cosim_obs_config_sizeof(void) { return (int)sizeof(cosim_obs_config_t); }

@@ -187,4 +187,24 @@ __global__ __launch_bounds__(256) void fleet_stats_kernel(const float* info, int
   }
 }
 
+// Percentiles of the same metric columns (N2: core/reporter.py:429-442, 506-530 plots the full series; a fleet keeps a mergeable
+// sketch instead): one histogram per column, `nbins` equal bins over [0, hi[c]) (values are magnitudes; column 1..3, the signed base
+// velocities, are binned by magnitude too), the last bin also takes everything above the range.  hist is [K][nbins] doubles, summed
+// over steps and -- by the caller -- over ranks.
+__global__ __launch_bounds__(256) void fleet_hist_kernel(const float* info, int n, int info_dim, int nu, const float* cmd, int cmd_stride,
+                                                         int ncmd, const float* hi, int nbins, double* hist) {
+  const int K = 4 + nu + ncmd, t = threadIdx.x, c = t & 31, g = t >> 5;
+  if (c >= K) return;
+  const float scale = (float)nbins / hi[c];
+  for (int r = blockIdx.x * 8 + g; r < n; r += gridDim.x * 8) {
+    const float* row = info + (size_t)r * info_dim;
+    float v;
+    if (c < 4 + nu) v = fabsf(row[c]);
+    else { const int i = c - 4 - nu; v = fabsf(cmd[(size_t)r * cmd_stride + i] - row[1 + i]); }
+    int b = (int)(v * scale);
+    b = b < 0 ? 0 : (b >= nbins ? nbins - 1 : b);
+    atomicAdd(&hist[(size_t)c * nbins + b], 1.0);
+  }
+}
+
 }  // namespace cosim

@@ -63,13 +63,17 @@ class Runner:
                 out[k] = v
         return out
 
-    def test(self, max_steps: Optional[int] = None, on_step: Optional[Callable] = None) -> int:
-        """Run until every env is done (no auto-reset) or ``max_steps`` control steps (auto-reset); returns steps run."""
+    def test(self, max_steps: Optional[int] = None, on_step: Optional[Callable] = None, before_step: Optional[Callable] = None) -> int:
+        """Run until every env is done (no auto-reset) or ``max_steps`` control steps (auto-reset); returns steps run.
+        ``before_step(k)`` runs at the top of iteration k, where the reference's UI thread has written the key-driven command and
+        push flags the loop is about to read (core/tester.py:39,80: ``user_command`` / ``_push_event``)."""
         env = self.env
         state, _ = env.reset()
         steps = 0
         done_all, done_seen = False, None
         while not done_all and not self._stop and (max_steps is None or steps < max_steps):
+            if before_step is not None:
+                before_step(steps)
             env.receive_user_command(self.user_command)            # tester.py:68
             action = self.policy.get_action(state)                 # :70
             if self._push_event:

@@ -174,6 +174,13 @@ int cosim_lstm_cell(const float* x_dev, const float* h_dev, const float* c_dev, 
 int cosim_fleet_stats(const float* info_dev, int n, int info_dim, int nu, const float* cmd_dev, int cmd_stride, int ncmd, double* acc_dev,
                       void* stream);
 
+/* Percentiles for the same columns (reference core/reporter.py:429-442, 506-530 keeps and plots every sample of one env; a fleet
+ * keeps a mergeable sketch): adds this step's rows to hist_dev, double[K][nbins], bin b of column c = magnitudes in
+ * [b, b + 1) * hi_dev[c] / nbins (the last bin also takes what lies above hi_dev[c]).  Sums over steps and ranks are percentiles'
+ * sufficient statistic; cosim_amd/reporter.py turns them into p5 / p50 / p95. */
+int cosim_fleet_hist(const float* info_dev, int n, int info_dim, int nu, const float* cmd_dev, int cmd_stride, int ncmd, const float* hi_dev,
+                     int nbins, double* hist_dev, void* stream);
+
 const char* cosim_last_error(void);
 int cosim_model_sizeof(void);
 int cosim_obs_config_sizeof(void);

@@ -1006,6 +1006,92 @@ def test_cli_rollout_with_onnx_policy_on_device(tmp_path):
     assert np.isfinite([v["mean"] for v in out["metrics"].values()]).all()
 
 
+def test_cli_session_file_scripts_commands_and_pushes_over_time(tmp_path):
+    """N4 as SURVEY 8f specifies it: YAML in, report out, the user's key-driven commands as a time series (reference
+    ui/main_window.py:272-290 -> core/tester.py:41-46) and the push button as a schedule, applied every loop iteration while held
+    (core/tester.py:80-81).  The traced env's info stream shows the command switching at the scripted step and the base velocity
+    pinned to the push while it is held."""
+    import json
+    import yaml
+    from cosim_amd import cli
+    rep = tmp_path / "report.json"
+    sess = {"env": {"id": "flamingo_light_v1", "terrain": "flat", "max_duration": 120.0},
+            "engine": {"num_envs": 32, "seed": 5},
+            "random": {"sensor_noise": "none", "action_delay_prob": 0.0},
+            "policy": {"kind": "random-mlp"},
+            "steps": 50,
+            "commands": [[0, 0.5, 0.0, 0.0, 0.0], [20, 1.0, 0.0, 0.25, 0.0], [35, -0.5, 0.0, 0.0, 0.1]],
+            "pushes": [[10, 14, 0.8, 0.0, 0.0]],
+            "report": str(rep), "trace_env": 4, "percentiles": True}
+    cfg = tmp_path / "session.yaml"
+    cfg.write_text(yaml.safe_dump(sess))
+    assert cli.main(["--config", str(cfg)]) == 0
+    out = json.loads(rep.read_text())
+    tr = out["trace"]
+    assert out["control_steps"] == 50 and out["envs"] == 32 and len(tr["user_command_0"]) == 50
+    c0, c2, c3 = np.array(tr["user_command_0"]), np.array(tr["user_command_2"]), np.array(tr["user_command_3"])
+    assert (c0[:20] == 0.5).all() and (c0[20:35] == 1.0).all() and (c0[35:] == -0.5).all()
+    assert (c2[:20] == 0.0).all() and (c2[20:35] == 0.25).all() and (c3[35:] == np.float32(0.1)).all()
+    # the push sets the base's planar velocity before the step, every step while held (the robot of this random policy spins, so the
+    # velocimeter's components rotate: compare planar speeds) -- against the same session without the push: identical before step 10
+    # (same seed, same everything), faster while held, and different from there on
+    sess2 = dict(sess, pushes=[], report=str(tmp_path / "nopush.json"))
+    cfg2 = tmp_path / "nopush.yaml"
+    cfg2.write_text(yaml.safe_dump(sess2))
+    assert cli.main(["--config", str(cfg2)]) == 0
+    tr0 = json.loads((tmp_path / "nopush.json").read_text())["trace"]
+    sp, sp0 = np.hypot(tr["lin_vel_x"], tr["lin_vel_y"]), np.hypot(tr0["lin_vel_x"], tr0["lin_vel_y"])
+    assert np.array_equal(np.array(tr["state"])[:10], np.array(tr0["state"])[:10]) and np.array_equal(sp[:10], sp0[:10])
+    # (the velocimeter reads the last substep's forward pass, 15 ms of wheel and caster dynamics after the push was applied)
+    assert sp[10] > sp0[10] + 0.3 and sp[10:14].mean() > sp0[10:14].mean() + 0.1, (sp[8:16], sp0[8:16])
+    assert not np.array_equal(np.array(tr["state"])[14:], np.array(tr0["state"])[14:])
+    # a flag on the command line overrides the file
+    rep2 = tmp_path / "r2.json"
+    assert cli.main(["--config", str(cfg), "--steps", "12", "--report", str(rep2)]) == 0
+    assert json.loads(rep2.read_text())["control_steps"] == 12
+    # N2: the percentiles of the fleet report
+    pc = out["percentiles"]
+    assert set(pc) == set(out["metrics"]) and pc["abs_torque_0"]["p5"] <= pc["abs_torque_0"]["p50"] <= pc["abs_torque_0"]["p95"]
+    bad = tmp_path / "bad.yaml"
+    bad.write_text(yaml.safe_dump({"envs": {}}))
+    with pytest.raises(SystemExit):
+        cli.main(["--config", str(bad)])
+
+
+def test_fleet_percentiles_match_the_samples():
+    """N2 ("fleet aggregates (mean/percentiles of tracking error, torque, action-RMSE)"; the reference plots every sample
+    of its one env, core/reporter.py:429-442, 506-530): p5 / p50 / p95 from the device-side histograms against numpy quantiles of
+    the very samples, to one bin width; histograms of two halves of the run add up to the whole (what the all-reduce relies on)."""
+    import torch
+    from cosim_amd.batched_env import BatchedEnv
+    from cosim_amd.config import make_config
+    from cosim_amd.reporter import NBINS, FleetReporter
+    env = BatchedEnv(make_config("flamingo_light_v1", num_envs=700, seed=3), num_envs=700, seed=3, auto_reset=True)
+    rep, first, second = (FleetReporter(env, percentiles=True) for _ in range(3))
+    env.reset()
+    env.receive_user_command(np.array([0.5, -0.2, 0.3, 0.0], dtype=np.float32))
+    g = torch.Generator(device=env.device).manual_seed(1)
+    rows = []
+    for t in range(30):
+        _, _, _, info = env.step(0.3 * torch.randn((700, 4), device=env.device, generator=g))
+        rep.write_info(info)
+        (first if t < 15 else second).write_info(info)
+        cmd = torch.stack([info[f"user_command_{i}"] for i in range(3)], dim=1)
+        meas = torch.stack([info["lin_vel_x"], info["lin_vel_y"], info["ang_vel_yaw"]], dim=1)
+        rows.append(torch.cat([info["action_diff_RMSE"][:, None].abs(), meas.abs(), info["torque"].abs(), (cmd - meas).abs()], dim=1).cpu().numpy())
+    x = np.concatenate(rows)                                      # [30 * 700, 11]
+    pc = rep.percentiles()
+    assert list(pc) == rep.names and float(rep.hist.sum()) == 30 * 700 * len(rep.names)
+    for i, name in enumerate(rep.names):
+        w = pc[name]["bin_width"]
+        assert w == pytest.approx(float(rep.hist_hi[i]) / NBINS)
+        for q in (5, 50, 95):
+            assert abs(pc[name][f"p{q}"] - np.quantile(np.minimum(x[:, i], rep.hist_hi[i]), q / 100.0)) <= 1.01 * w, (name, q)
+    assert torch.equal(first.hist + second.hist, rep.hist)
+    assert rep.summary()["percentiles"]["tracking_err_0"]["p50"] == pytest.approx(pc["tracking_err_0"]["p50"])
+    env.close()
+
+
 def test_graph_captured_rollout_equals_eager(tmp_path):
     """One control step (ONNX policy -> cosim_step -> fleet report) captured in a HIP graph and replayed gives the bits of the
     eager loop: the engine's launch is capturable on the caller's stream (no hidden host work in cosim_step)."""

@@ -89,6 +89,114 @@ def test_compiled_model_facts_light_v1():
     assert np.allclose(fl[6:14], 0.1) and np.allclose(fl[14:], 0.0) and np.allclose(fl[:6], 0.0)
 
 
+def _hinge_ranges(cm):
+    b = cm.blob
+    return {cm.joint_names[j]: tuple(get_field(b, "jnt_range")[j]) for j in range(b.njnt) if get_field(b, "jnt_limited")[j]}
+
+
+def test_compiled_model_facts_flamingo_p_v3():
+    """SURVEY App. A, column flamingo_p_v3 (facts read off envs/flamingo_p_v3/assets/xml/flamingo_p_v3.xml by hand)."""
+    cm = compile_model(make_config("flamingo_p_v3", random=PARITY_RANDOM))
+    b = cm.blob
+    assert (b.nq, b.nv, b.nu, b.nbody - 1, b.neq) == (15, 14, 8, 9, 0)                 # 9 bodies + world; free + 8 hinges
+    assert np.array(get_field(b, "body_mass")[:b.nbody]).sum() == pytest.approx(16.51937, abs=1e-5)
+    # action order = XML actuator order: L/R hip, L/R shoulder, L/R leg, L/R wheel -> qpos 7, 11, 8, 12, 9, 13, 10, 14
+    assert list(get_field(b, "ctl_qadr")[:8]) == [7, 11, 8, 12, 9, 13, 10, 14]
+    assert list(get_field(b, "ctl_gear")[:8]) == [1, 1, 1, 1, -1.5, -1.5, 1, 1]          # legs geared -1.5 (flamingo_p_v3.py:161)
+    assert list(get_field(b, "ctl_velmode")[:8]) == [0, 0, 0, 0, 0, 0, 1, 1]             # wheels are velocity-PD
+    assert np.allclose(get_field(b, "gravity"), [0, 0, -9.807]) and b.timestep == 0.005
+    assert np.array(get_field(b, "init_qpos")[:3]).tolist() == [0.0, 0.0, 0.61282]       # initial_qpos (:249-255)
+    assert b.term_mode == 1 and b.nterm_body == 5 and b.init_noise_nq == 8               # cfrc_ext rule; noise on every hinge
+    rng = _hinge_ranges(cm)
+    assert rng["left_hip_joint"] == pytest.approx((-0.6, 0.6)) and rng["left_shoulder_joint"] == pytest.approx((-1.6, 1.53))
+    assert rng["left_leg_joint"] == pytest.approx((-0.64, 1.35)) and "left_wheel_joint" not in rng      # range "0 0": unlimited
+    # frictionloss: only the `wheels` default class is rewritten by XMLManager step 6 (SURVEY App. D7); the hinges keep the 0.1 of
+    # the XML's top-level joint default -- and so do the SIX dofs of the base: it is declared <joint type="free"> (flamingo_p_v3.xml:42),
+    # not <freejoint>, so the joint defaults (frictionloss 0.1, armature 0.01) apply to it; only its damping is overridden to 0
+    fl = np.array(get_field(b, "dof_frictionloss")[:b.nv])
+    assert np.allclose(fl, 0.1) and np.allclose(get_field(b, "dof_armature")[:6], 0.01) and np.allclose(get_field(b, "dof_damping")[:6], 0.0)
+    assert b.ngeom == 8 and b.npair > 0 and set(get_field(b, "geom_type")[:8]) == {7}    # eight hulls, self-collision on (masks 1 / 1)
+
+
+def test_compiled_model_facts_w4_p_v2():
+    """SURVEY App. A, column w4_p_v2."""
+    cm = compile_model(make_config("w4_p_v2", terrain="rocky_hard", random=PARITY_RANDOM))
+    b = cm.blob
+    assert (b.nq, b.nv, b.nu, b.nbody - 1, b.neq) == (23, 22, 16, 17, 0)
+    assert np.array(get_field(b, "body_mass")[:b.nbody]).sum() == pytest.approx(36.20476, abs=1e-5)
+    # FL 7-10, FR 11-14, RL 15-18, RR 19-22 (hip, shoulder, leg, wheel); the XML's actuator order is leg by leg
+    assert sorted(get_field(b, "ctl_qadr")[:16]) == list(range(7, 23))
+    gear = np.array(get_field(b, "ctl_gear")[:16]); qadr = np.array(get_field(b, "ctl_qadr")[:16])
+    assert sorted(qadr[gear == -1.5].tolist()) == [9, 13, 17, 21] and (gear[gear != -1.5] == 1).all()   # the four legs
+    assert sorted(qadr[np.array(get_field(b, "ctl_velmode")[:16]) == 1].tolist()) == [10, 14, 18, 22]   # the four wheels
+    assert np.allclose(get_field(b, "gravity"), [0, 0, -9.807])
+    assert np.array(get_field(b, "init_qpos")[:3]).tolist() == [0.0, 0.0, 0.47957] and b.term_mode == 0
+    assert b.ngeom == 17 and set(get_field(b, "geom_type")[:17]) == {7}
+    # rocky_hard: 512 x 512 samples, half-extent 140 m, z 0.25 m, base 0.1 m (w4_p_v2.xml:179)
+    assert (b.hfield_nrow, b.hfield_ncol) == (512, 512) and list(get_field(b, "hfield_size")) == pytest.approx([140, 140, 0.25, 0.1])
+    assert cm.hfield.min() == 0.0 and cm.hfield.max() == 1.0 and len(np.unique(cm.hfield)) == 101      # 101 grey levels (App. A)
+
+
+def test_compiled_model_facts_humanoid_p_v0():
+    """SURVEY App. A, column humanoid_p_v0."""
+    cm = compile_model(make_config("humanoid_p_v0", terrain="stairs_up_hard", random=PARITY_RANDOM))
+    b = cm.blob
+    assert (b.nq, b.nv, b.nu, b.nbody - 1, b.neq) == (30, 29, 23, 25, 0)                # 25 bodies incl. the jointless imu_link
+    assert np.array(get_field(b, "body_mass")[:b.nbody]).sum() == pytest.approx(61.80264, abs=1e-5)
+    assert sorted(get_field(b, "ctl_qadr")[:23]) == list(range(7, 30))                  # torso 7; arms 8-17; legs 18-29
+    assert (np.array(get_field(b, "ctl_gear")[:23]) == 1).all() and (np.array(get_field(b, "ctl_velmode")[:23]) == 0).all()
+    assert np.allclose(get_field(b, "gravity"), [0, 0, -9.807])
+    assert np.array(get_field(b, "init_qpos")[:3]).tolist() == [0.0, 0.0, 1.105] and b.term_mode == 0
+    gt = list(get_field(b, "geom_type")[:b.ngeom])
+    assert (gt.count(6), gt.count(5), gt.count(7)) == (4, 16, 2)                        # 4 boxes, 16 cylinders, 2 mesh feet
+    assert b.heightmap_miss == 5.0                                                      # utils/mujoco_utils.py:141 (z_min_world = -5)
+    # stairs_up_hard: the 1024 x 1024 PNG overrides the XML's nrow / ncol = 512; half-extent 5 m, z 0.825 m (humanoid_p_v0.xml:220)
+    assert (b.hfield_nrow, b.hfield_ncol) == (1024, 1024) and list(get_field(b, "hfield_size"))[:3] == pytest.approx([5, 5, 0.825])
+    assert len(np.unique(cm.hfield)) == 6 and cm.hfield[512, 512] == 0.0                # six levels; the spawn point is at elevation 0
+
+
+def test_hfield_png_conventions_known_answer(tmp_path):
+    """N3 / A2 (SURVEY 8a A2 marks these "[upstream, verify]"): how a terrain PNG becomes elevation.  The convention ASSUMED here,
+    and stated so that a MuJoCo cross-check can falsify it: (1) grey levels are normalised by the file's own min and max to [0, 1];
+    (2) image rows are flipped -- the image's LAST row is hfield row 0, the row at y = -size_y; (3) column c sits at
+    x = -size_x + c * 2 size_x / (ncol - 1), row r at y = -size_y + r * 2 size_y / (nrow - 1); (4) the surface height is
+    ground_z + size_z * elevation; (5) the file's resolution overrides the XML's nrow / ncol.  A hand-built 4 x 4 file pins the
+    loader; the oracle's vertical ray and the compiled field pin (3) and (4) on a shipped terrain."""
+    from PIL import Image
+    from cosim_amd.compile import _load_hfield
+    from oracle.oracle import Oracle
+    img = np.array([[10, 20, 30, 40],          # top row of the image
+                    [50, 60, 70, 80],
+                    [90, 100, 110, 120],
+                    [130, 170, 210, 250]], dtype=np.uint8)     # bottom row of the image
+    path = tmp_path / "hand.png"
+    Image.fromarray(img, mode="L").save(path)
+    h = _load_hfield(str(path))
+    assert h.shape == (4, 4) and h.dtype == np.float32
+    np.testing.assert_allclose(h[0], (np.array([130, 170, 210, 250]) - 10) / 240.0, rtol=1e-6)      # (2): bottom image row first
+    np.testing.assert_allclose(h[3], (np.array([10, 20, 30, 40]) - 10) / 240.0, rtol=1e-6)
+    assert h.min() == 0.0 and h.max() == 1.0                                                         # (1)
+    flat = tmp_path / "flat.png"
+    Image.fromarray(np.full((3, 5), 255, dtype=np.uint8), mode="L").save(flat)
+    assert _load_hfield(str(flat)).shape == (3, 5) and (_load_hfield(str(flat)) == 0.0).all()        # constant image -> elevation 0
+    # (3), (4), (5) on stairs_up_hard through the compiled model and the oracle's vertical ray (mj_rayHfield restatement)
+    cm = compile_model(make_config("humanoid_p_v0", terrain="stairs_up_hard", random=PARITY_RANDOM))
+    b = cm.blob
+    sx, sy, sz, _ = get_field(b, "hfield_size")
+    nr, nc = cm.hfield.shape
+    assert (nr, nc) == (1024, 1024)
+    o = Oracle(cm)
+    gz = get_field(b, "ground_pos")[2]
+    rng = np.random.default_rng(0)
+    for r, c in rng.integers(1, 1023, size=(12, 2)):
+        x, y = -sx + c * 2 * sx / (nc - 1), -sy + r * 2 * sy / (nr - 1)
+        assert 10.0 - o.ray_down(x, y, 10.0) == pytest.approx(gz + sz * cm.hfield[r, c], abs=1e-9), (r, c)
+    src = np.asarray(Image.open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "cosim_amd", "assets", "terrain",
+                                             "stairs_up_hard.png")).convert("L"), dtype=np.float64)
+    r, c = 100, 900
+    assert cm.hfield[r, c] == pytest.approx((src[nr - 1 - r, c] - src.min()) / (src.max() - src.min()), abs=1e-7)
+
+
 @pytest.mark.parametrize("env_id", ["flamingo_light_v1", "flamingo_p_v3"])
 def test_env_constants_batched_equals_single(env_id):
     cm = compile_model(make_config(env_id, random=PARITY_RANDOM))
