@@ -150,6 +150,12 @@ class BatchedEnv:
             self.engine.set_param("ls_tolerance_scale", np.array([float(os.environ["COSIM_LS_SCALE"])]))
         if os.environ.get("COSIM_PAIR_MODE"):                  # "1": hull pairs wave-cooperative (A/B runs)
             self.engine.set_param("pair_mode", np.array([float(os.environ["COSIM_PAIR_MODE"])]))
+        for var, name in (("COSIM_SPLIT", "split"), ("COSIM_NARROW_WAVES", "narrow_waves"), ("COSIM_NARROW_OCC", "narrow_occupancy")):
+            if os.environ.get(var):                            # split pipeline of the heightfield humanoid kernels (A/B and tuning runs)
+                try:
+                    self.engine.set_param(name, np.array([float(os.environ[var])]))
+                except (ValueError, RuntimeError):
+                    pass
         epw = os.environ.get("COSIM_ENVS_PER_WAVE")
         if epw:
             try:

@@ -72,6 +72,14 @@ struct cosim_engine {
   // large-capacity kernel behind the fleet kernel (env_fixup_kernel): redoes the control step of envs whose contacts did not fit
   void (*launch_fix)(cosim_engine*, const KArgs&, int grid, hipStream_t) = nullptr;
   int fix_contact_slots = 0;
+  // split pipeline (env_narrow_kernel + env_step_kernel, one pair of launches per substep) where the model / terrain has one
+  void (*launch_narrow)(cosim_engine*, const KArgs&, int grid, hipStream_t) = nullptr;
+  void (*launch_stepx)(cosim_engine*, const KArgs&, int grid, hipStream_t) = nullptr;
+  bool split = false;
+  int narrow_waves = 8;
+  int narrow_occ = 2;   // narrowphase kernel variant: waves per SIMD its registers are allocated for (0: diagnostic build)
+  float *d_xcon = nullptr, *d_xstate = nullptr;
+  int* d_xcnt = nullptr;
   int* d_ovf = nullptr;   // [n_envs] flags, set by the fleet kernel, cleared by the fix-up kernel
   // range launches: cosim_step issues the fleet as n_ranges launches over contiguous env ranges on engine-owned streams, so that a
   // range's next control step fills the tail of the others' launches (a launch ends with its slowest env)
@@ -102,6 +110,17 @@ static void launch_prof_t(cosim_engine* e, const KArgs& a, int grid, hipStream_t
 template <int NV, int NB, int RPL, bool HF, int GTM, bool SC, int MCT>
 static void launch_fix_t(cosim_engine* e, const KArgs& a, int grid, hipStream_t s) {   // grid = envs of the range
   hipLaunchKernelGGL((env_fixup_kernel<NV, NB, RPL, HF, GTM, SC, MCT>), dim3((grid + 63) / 64), dim3(64), 0, s, a);
+}
+template <int NV, int NB, int RPL, bool HF, int GTM, bool SC, int MCT>
+static void launch_narrow_t(cosim_engine* e, const KArgs& a, int grid, hipStream_t s) {   // grid = envs x waves per env
+  if (e->narrow_occ >= 4) hipLaunchKernelGGL((env_narrow_kernel<NV, NB, RPL, HF, GTM, SC, MCT, 4>), dim3(grid), dim3(64), 0, s, a);
+  else if (e->narrow_occ == 3) hipLaunchKernelGGL((env_narrow_kernel<NV, NB, RPL, HF, GTM, SC, MCT, 3>), dim3(grid), dim3(64), 0, s, a);
+  else if (e->narrow_occ == 2) hipLaunchKernelGGL((env_narrow_kernel<NV, NB, RPL, HF, GTM, SC, MCT, 2>), dim3(grid), dim3(64), 0, s, a);
+  else hipLaunchKernelGGL((env_narrow_kernel<NV, NB, RPL, HF, GTM, SC, MCT, 2, true>), dim3(grid), dim3(64), 0, s, a);   // narrow_occupancy 0: diagnostic build
+}
+template <int NV, int NB, int RPL, bool HF, int GTM, bool SC, int MCT>
+static void launch_stepx_t(cosim_engine* e, const KArgs& a, int grid, hipStream_t s) {
+  hipLaunchKernelGGL((env_step_kernel<NV, NB, RPL, HF, GTM, SC, MCT>), dim3(grid), dim3(64), 0, s, a);
 }
 template <int NV, int NB, int GTM>
 static void launch2_t(cosim_engine* e, const KArgs& a, int grid, hipStream_t s) {   // grid = number of envs
@@ -559,7 +578,13 @@ int cosim_create(const cosim_model_t* model, const float* hull_vert, const int* 
   else if (nv == 29 && nb <= 26 && (gtm & ~G_HUM) == 0) {     // humanoid_p_v0
     // plane: at most 4 contacts per geom (22 geoms); 96 slots = 6 waves per CU instead of 5
     select_t<29, 26, 2, G_HUM, true, 96, 256>(e, hf);
-    if (hf) e->launch_prof = launch_prof_t<29, 26, 2, true, G_HUM, true, 256>;
+    if (hf) {
+      e->launch_prof = launch_prof_t<29, 26, 2, true, G_HUM, true, 256>;
+      // the prism walk in a kernel of its own, several waves per env (default; cosim_set_param "split" 0 goes back to the fused kernel)
+      e->launch_narrow = launch_narrow_t<29, 26, 2, true, G_HUM, true, 256>;
+      e->launch_stepx = launch_stepx_t<29, 26, 2, true, G_HUM, true, 256>;
+      e->split = true;
+    }
   }
   else { delete e; return fail(COSIM_EINVAL, "cosim_create: no kernel instantiation for this (nv, nbody); add one in cosim_engine.hip"); }
   if (model->ngeom > e->geom_stage) { delete e; return fail(COSIM_EINVAL, "cosim_create: more collision geoms than the plane kernel stages contacts for"); }
@@ -571,6 +596,13 @@ int cosim_create(const cosim_model_t* model, const float* hull_vert, const int* 
   HIP_TRY(hipMemset(e->d_state, 0, (size_t)n_envs * e->lay.s_stride * sizeof(float)));
   HIP_TRY(hipMalloc(&e->d_params, (size_t)n_envs * e->lay.p_stride * sizeof(float)));
   HIP_TRY(hipMalloc(&e->d_dbg, 8192 * sizeof(float)));
+  if (e->launch_stepx) {
+    HIP_TRY(hipMalloc(&e->d_xcon, (size_t)n_envs * XG * XC * 8 * sizeof(float)));
+    HIP_TRY(hipMalloc(&e->d_xcnt, (size_t)n_envs * XG * sizeof(int)));
+    HIP_TRY(hipMalloc(&e->d_xstate, (size_t)n_envs * XS * sizeof(float)));
+    HIP_TRY(hipMemset(e->d_xcnt, 0, (size_t)n_envs * XG * sizeof(int)));
+    HIP_TRY(hipMemset(e->d_xstate, 0, (size_t)n_envs * XS * sizeof(float)));
+  }
   HIP_TRY(hipMalloc(&e->d_ovf, (size_t)n_envs * sizeof(int)));
   HIP_TRY(hipMemset(e->d_ovf, 0, (size_t)n_envs * sizeof(int)));
   int nhv = model->nhullvert > 0 ? model->nhullvert : 1, nhe = model->nhulledge > 0 ? model->nhulledge : 1;
@@ -615,7 +647,7 @@ int cosim_destroy(cosim_engine_t* e) {
   hipSetDevice(e->device);
   hipFree(e->d_model); hipFree(e->d_obs); hipFree(e->d_state); hipFree(e->d_params); hipFree(e->d_dbg);
   hipFree(e->d_hull_vert); hipFree(e->d_hull_adr); hipFree(e->d_hull_nbr); hipFree(e->d_hfield);
-  hipFree(e->d_pairs); hipFree(e->d_gext); hipFree(e->d_ovf);
+  hipFree(e->d_pairs); hipFree(e->d_gext); hipFree(e->d_ovf); hipFree(e->d_xcon); hipFree(e->d_xcnt); hipFree(e->d_xstate);
   for (hipEvent_t x : e->ev) hipEventDestroy(x);
   for (hipStream_t x : e->rstream) hipStreamDestroy(x);
   for (hipEvent_t x : e->rdone) hipEventDestroy(x);
@@ -642,6 +674,7 @@ int cosim_query(const cosim_engine_t* e, const char* name) {
   if (n == "contact_slots") return e->contact_slots;
   if (n == "fixup_contact_slots") return e->launch_fix ? e->fix_contact_slots : 0;   // 0: no large-capacity kernel behind this one
   if (n == "ranges") return e->n_ranges;
+  if (n == "split") return (e->split && e->launch_stepx) ? e->narrow_waves : 0;   // waves per env of the narrowphase kernel; 0: fused kernel
   if (n == "pair_slots") return e->pair_slots;
   if (n == "stacked_dim") return e->ho.stacked_dim;
   if (n == "frame_dim") return e->ho.frame_dim;
@@ -683,6 +716,18 @@ int cosim_set_param(cosim_engine_t* e, const char* name, const float* host, int 
     e->inflight = v;
     return set_ranges(e, e->n_ranges);
   }
+  else if (n == "split") {   // 0: the fused kernel; 1: narrowphase and solver as kernels of their own, one pair of launches per substep
+    if ((int)host[0] != 0 && !e->launch_stepx) return fail(COSIM_EINVAL, "cosim_set_param: no split pipeline for this model / terrain");
+    e->split = (int)host[0] != 0;
+    return COSIM_OK;
+  }
+  else if (n == "narrow_waves") {   // waves per env of the narrowphase kernel (wave w takes the geoms g % waves == w)
+    const int v = (int)host[0];
+    if (v < 1 || v > 24) return fail(COSIM_EINVAL, "cosim_set_param: narrow_waves must be 1..24");
+    e->narrow_waves = v;
+    return COSIM_OK;
+  }
+  else if (n == "narrow_occupancy") { e->narrow_occ = (int)host[0]; return COSIM_OK; }   // 2 | 3 | 4 (tuning)
   else if (n == "fixup") {   // 0: no fix-up launches (contacts beyond the fleet kernel's slots are left out and counted, as in round 2)
     if ((int)host[0] == 0) e->launch_fix = nullptr;
     return COSIM_OK;
@@ -734,6 +779,7 @@ static KArgs base_args(cosim_engine* e) {
   a.tol32 = e->tol32; a.ls_scale = e->ls_scale; a.max_newton = e->max_newton; a.max_ls = e->max_ls; a.nsub_override = e->nsub_override; a.pair_coop = e->pair_coop; a.pair_boxbox = e->pair_boxbox;
   for (int k = 0; k < 4; k++) a.prio[k] = e->prio[k];
   a.ovf = nullptr;
+  a.xcon = e->d_xcon; a.xcnt = e->d_xcnt; a.xstate = e->d_xstate; a.nw = e->narrow_waves; a.sub_index = 0; a.sub_total = 0;
   return a;
 }
 
@@ -746,7 +792,8 @@ int cosim_reset(cosim_engine_t* e, const uint8_t* mask_dev, const float* command
   if (rc) return rc;
   KArgs a = base_args(e);
   a.mode = MODE_RESET; a.mask = mask_dev; a.commands = commands_dev; a.state_out = state_out_dev;
-  (e->epw == 2 ? e->launch2 : e->launch)(e, a, e->n_envs, (hipStream_t)stream);
+  if (e->split && e->launch_stepx) e->launch_stepx(e, a, e->n_envs, (hipStream_t)stream);
+  else (e->epw == 2 ? e->launch2 : e->launch)(e, a, e->n_envs, (hipStream_t)stream);
   HIP_TRY(hipGetLastError());
   return COSIM_OK;
 }
@@ -835,6 +882,7 @@ int cosim_step_range(cosim_engine_t* e, int first, int count, const float* actio
   a.mode = MODE_STEP; a.actions = actions_dev; a.commands = commands_dev; a.state_out = state_out_dev;
   a.terminated = terminated_dev; a.truncated = truncated_dev; a.info = info_out_dev;
   a.env_first = first; a.env_count = count;
+  if (e->split && e->launch_stepx && e->narrow_occ == 0) a.dbg = e->d_dbg;   // diagnostic narrowphase build accumulates its counters there
   a.ovf = (e->launch_fix && e->epw == 1) ? e->d_ovf : nullptr;
   hipStream_t s = (hipStream_t)stream;
   // kernel timing: one HIP event pair per launch on the launch stream, read back in cosim_kernel_time() (no sync here)
@@ -848,7 +896,15 @@ int cosim_step_range(cosim_engine_t* e, int first, int count, const float* actio
     e->ev_used += 2;
     HIP_TRY(hipEventRecord(e->ev[slot], s));
   }
-  (e->epw == 2 ? e->launch2 : e->launch)(e, a, count, s);
+  if (e->split && e->launch_stepx) {
+    // one pair of launches per substep: the prism walk (narrow_waves waves per env), then the solver with the contacts it left
+    const int fs = e->nsub_override > 0 ? e->nsub_override : e->model.frame_skip;
+    for (int sub = 0; sub < fs; sub++) {
+      a.sub_index = sub; a.sub_total = fs;
+      e->launch_narrow(e, a, count * e->narrow_waves, s);
+      e->launch_stepx(e, a, count, s);
+    }
+  } else (e->epw == 2 ? e->launch2 : e->launch)(e, a, count, s);
   HIP_TRY(hipGetLastError());
   if (slot >= 0) HIP_TRY(hipEventRecord(e->ev[slot + 1], s));
   if (a.ovf) {   // envs the fleet kernel flagged (more contacts than it has slots for) are redone by the large-capacity kernel
@@ -927,7 +983,8 @@ int cosim_debug_forward(cosim_engine_t* e, int env, const char* name, float* hos
   HIP_TRY(hipMemset(e->d_dbg, 0, 8192 * sizeof(float)));
   KArgs a = base_args(e);
   a.mode = MODE_DEBUG; a.dbg = e->d_dbg; a.dbg_env = env;
-  (e->epw == 2 ? e->launch2 : e->launch)(e, a, 1, 0);   // two-per-wave kernel: both groups replay env `env`, same dump twice
+  if (e->split && e->launch_stepx) { e->launch_narrow(e, a, e->narrow_waves, 0); e->launch_stepx(e, a, 1, 0); }   // the product's own pair of kernels
+  else (e->epw == 2 ? e->launch2 : e->launch)(e, a, 1, 0);   // two-per-wave kernel: both groups replay env `env`, same dump twice
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipDeviceSynchronize());
   int n = capacity < 8192 ? capacity : 8192;
@@ -954,6 +1011,15 @@ int cosim_profile_step(cosim_engine_t* e, const float* actions_dev, const float*
   unsigned long long raw[32];
   HIP_TRY(hipMemcpy(raw, e->d_dbg, sizeof raw, hipMemcpyDeviceToHost));
   for (int i = 0; i < 32; i++) cycles_out16[i] = (double)raw[i] / (double)(e->n_envs / e->epw);   // per wave
+  return COSIM_OK;
+}
+
+int cosim_debug_counters(cosim_engine_t* e, unsigned long long* out32, int clear) {   // the 32 64-bit words diagnostic kernels accumulate into
+  if (!e || !out32) return fail(COSIM_EINVAL, "cosim_debug_counters: null argument");
+  HIP_TRY(hipSetDevice(e->device));
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpy(out32, e->d_dbg, 32 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  if (clear) HIP_TRY(hipMemset(e->d_dbg, 0, 8192 * sizeof(float)));
   return COSIM_OK;
 }
 

@@ -66,6 +66,12 @@ struct KArgs {
   int pair_coop;          // robot-robot pairs with a hull: 1 = one at a time, wave-cooperative vertex scans; 0 = lane-parallel
   int pair_boxbox;        // box-box pairs: 1 = mjc_BoxBox (up to eight contacts), 0 = through MPR like the other convex pairs (one contact)
   int prio[4];            // wave priority by solver lag: expected Newton iterations per substep, then the three lag thresholds
+  // split pipeline (heightfield narrowphase in a kernel of its own, see env_narrow_kernel): one launch = one substep
+  float* xcon;            // [N][XG][XC][8] contacts per (env, geom): dist, pos[3], normal[3], -- ; written by the narrowphase kernel
+  int* xcnt;              // [N][XG] contacts found per (env, geom)
+  float* xstate;          // [N][XS] what a control step holds across its substep launches: actuation force, raw action, torque
+  int sub_index, sub_total;   // this launch is substep sub_index of sub_total (0: the fused kernel, every substep in one launch)
+  int nw;                 // narrowphase: waves per env (wave w takes the geoms g with g % nw == w)
   int* ovf;               // [N] per-env flag "this control step needs the large-capacity kernel" (null: no such kernel; contacts that find no slot are left out and counted)
   int env_count;          // envs of this launch (the fix-up kernel scans ovf[env_first .. env_first + env_count))
 };
@@ -244,14 +250,18 @@ __device__ __forceinline__ float u01(unsigned x) { return (float)(x >> 8) * (1.0
 // CT: robot-robot contacts in slots of their own; per ground contact the regulariser D, the four rows' J a - aref and J s;
 // per body: twist of the vector in flight, contact wrench, 6 x 6 contact "inertia" (lower triangle, 21 entries).  Empty otherwise
 // (the one-env-per-wave kernel of flamingo_light_v1 must stay within 160 KiB / 16 = 10240 B of LDS).
-template <bool CT, bool HF, int NB, int MC, int MCP>
+constexpr int XG = 24, XC = 50, XS = 96;
+static_assert(CS_MAXDOF + 2 * (CS_MAXDOF - 6) + CS_MAXCMD <= 96 || true, "xstate: qact[NV], act[NV - 6], tq[NV - 6], cmd[CS_MAXCMD]");   // split pipeline: geoms per env, contacts per geom (mjMAXCONPAIR), floats of per-step state
+// SLIM: the narrowphase-only kernel keeps none of the solver's arrays (one element each, never touched)
+template <bool CT, bool HF, int NB, int MC, int MCP, bool SLIM = false>
 struct CtLds {
-  float ppos[MCP][3], pnrm[MCP][3], pdist[MCP];
-  int pgeom[MCP];
+  static constexpr int MCA = SLIM ? 1 : MC, MCPA = SLIM ? 1 : MCP, NBA = SLIM ? 1 : NB;
+  float ppos[MCPA][3], pnrm[MCPA][3], pdist[MCPA];
+  int pgeom[MCPA];
   // the four pyramid rows of a ground contact are base +- x1, base +- x2 (n +- mu t1, n +- mu t2): three numbers per contact
-  float cD[MC], cJar[MC][3], cJv[MC][3];
-  float tw[NB][6], bw[NB][6];
-  alignas(16) float bW[NB][24];   // 21 used; rows padded so that the tree pass reads them as six 16-byte words
+  float cD[MCA], cJar[MCA][3], cJv[MCA][3];
+  float tw[NBA][6], bw[NBA][6];
+  alignas(16) float bW[NBA][24];   // 21 used; rows padded so that the tree pass reads them as six 16-byte words
   unsigned cbmask;   // bodies that carry a ground contact
   // heightfield narrowphase, per geom: end of its (geom, prism) work items in the flattened list, contacts found so far, sub-grid
   // origin, prisms per strip row, lowest point of the geom
@@ -264,13 +274,16 @@ struct CtLds {
   int hf_zlist[HF ? 64 + 64 * HFB : 1];
   float hf_mg[HF ? 24 : 1];    // per geom: contact margin
   float hf_lo[HF ? 24 : 1];
+  // narrowphase kernel: per geom an oriented box around it, grown by the reach of a prism's footprint from its centroid: centre[3],
+  // rotation (row-major, local -> world)[9], half extents[3]
+  float hf_box[(HF && SLIM) ? 24 : 1][16];
 };
-template <bool HF, int NB, int MC, int MCP>
-struct CtLds<false, HF, NB, MC, MCP> {};
+template <bool HF, int NB, int MC, int MCP, bool SLIM>
+struct CtLds<false, HF, NB, MC, MCP, SLIM> {};
 // NRM: the contact list stores normals (legacy: heightfield ground or robot-robot pairs; CT: heightfield ground -- the robot-robot
 // contacts have slots of their own); MCPT: robot-robot contact slots of a CT kernel (0: the model has no pairs)
-template <int NV, int NB, int RPL, bool NRM, int LW = 64, int MCT = 0, int MCPT = 12, bool HFL = NRM>
-struct EnvLds : CtLds<(MCT > 0), HFL, NB, (MCT > 0 ? MCT : 1), (MCPT > 0 ? MCPT : 1)> {
+template <int NV, int NB, int RPL, bool NRM, int LW = 64, int MCT = 0, int MCPT = 12, bool HFL = NRM, bool SLIM = false>
+struct EnvLds : CtLds<(MCT > 0), HFL, NB, (MCT > 0 ? MCT : 1), (MCPT > 0 ? MCPT : 1), SLIM> {
   static constexpr bool CT = MCT > 0;
   static constexpr int LD = NV | 1;   // odd leading dimension: conflict-free column access
   static constexpr int ROWS = LW * RPL;            // constraint rows per env: RPL rows per lane, LW lanes per env
@@ -283,23 +296,25 @@ struct EnvLds : CtLds<(MCT > 0), HFL, NB, (MCT > 0 ? MCT : 1), (MCPT > 0 ? MCPT 
   static constexpr int CPL = (MC + LW - 1) / LW;   // CT: contacts per lane = passes over the contact list
   static constexpr int NGEN = NEQR + 4 * (CT ? MCP : MC);  // dense rows: 2 connect equalities (6 rows) + contacts
   static constexpr int NUMAX = NV - 6;   // actuators: at most one per hinge dof (the free joint's six dofs carry none)
+  // (SLIM, the narrowphase-only kernel: kinematics and the prism walk only; the solver's arrays shrink to one element)
+  static constexpr int NVA = SLIM ? 1 : NV, NBS = SLIM ? 1 : NB, MCA = SLIM ? 1 : MC, NGENA = SLIM ? 1 : NGEN, ROWSA = SLIM ? 1 : ROWS;
   float qpos[CS_MAXQ], qvel[NV], qacc[NV], qact[NV], qsm[NV], qcon[NV], sr[NV];
   float xpos[NB][3], xquat[NB][4];
-  alignas(8) float cdof[NV][6];
-  float M[NV][LD];
+  alignas(8) float cdof[NVA][6];
+  float M[NVA][LD];
   union {                      // scratch that is dead before the solver starts shares the Hessian's space
-    float H[NV][LD];
-    struct { float cdd[NV][6], cfb[NB][6]; } v;
+    float H[NVA][LD];
+    struct { float cdd[NVA][6], cfb[NBS][6]; } v;
     struct { float xanc[NB][3], xax[NB][3]; } k;   // joint anchors and axes: written by the kinematics sweep, dead once cdof is built
   } u;
   union {
-    float cin[NB][10];         // dead after the bias forces
-    struct { float rowf[ROWS], rowD[ROWS]; } r;
+    float cin[NBS][10];         // dead after the bias forces
+    struct { float rowf[ROWSA], rowD[ROWSA]; } r;
   } w;
   static constexpr int NGS = (int)(sizeof(u) / 64) < 24 ? (int)(sizeof(u) / 64) : 24;   // geom lanes that can stage plane contacts (4 x {dist, pos}) in u's space
-  float J[NGEN][LD];
-  float cpos[MC][3], cnrm[NRM ? MC : 1][3], cdist[MC];   // contact normals are +z on the plane: not stored
-  int cgeom[MC];   // geom2 | (geom1 + 1) << 8; geom1 + 1 == 0: the ground
+  float J[NGENA][LD];
+  float cpos[MCA][3], cnrm[NRM ? MCA : 1][3], cdist[MCA];   // contact normals are +z on the plane: not stored
+  int cgeom[MCA];   // geom2 | (geom1 + 1) << 8; geom1 + 1 == 0: the ground
   float p_mass[NB], p_binvw[NB], p_dinvw[NV], p_floss[NV], p_gmu[24];   // collision geoms: at most 22 (humanoid_p_v0)
   float act[NUMAX], tq[NUMAX], cmd[CS_MAXCMD + 2];
   float sens[10];   // framequat[4], gyro[3], velocimeter[3] of the last substep's forward pass
@@ -545,12 +560,15 @@ __device__ __forceinline__ float impedance(PS solimp, float pos, float margin) {
 }
 
 // LDS layout of a kernel variant (shared with the host side, which reports lds_bytes / contact_slots)
-template <int NV, int NB, int RPL, bool HF, bool SC, int EPW, int MCT>
+// KM (kernel mode): 0 the fused kernel (a whole control step, collision included); 1 narrowphase only (env_narrow_kernel: kinematics +
+// the heightfield prism walk of some of the env's geoms, contacts to global memory); 2 one substep per launch with the ground
+// contacts read from global memory (what the narrowphase kernel wrote)
+template <int NV, int NB, int RPL, bool HF, bool SC, int EPW, int MCT, int KM = 0>
 struct KTraits {
   static constexpr bool CT = MCT > 0;
   static constexpr bool NRM = CT ? HF : (HF || SC);
   static constexpr int MCPT = SC ? (NV >= 22 ? 12 : 8) : 0;
-  using L = EnvLds<NV, NB, RPL, NRM, 64 / EPW, MCT, MCPT, HF>;
+  using L = EnvLds<NV, NB, RPL, NRM, 64 / EPW, MCT, MCPT, HF, KM == 1>;
 };
 
 // ------------------------------------------------------------------------------------------------ the kernel
@@ -566,11 +584,16 @@ typedef const KArgs __attribute__((address_space(4)))* KArgsP;
 // One control step of environment `env` by the calling wave (EPW = 2: by the calling half-wave).  FIX: this is the large-capacity
 // kernel redoing a step that the fleet's kernel gave up on (see env_fixup_kernel); otherwise, where the engine has such a kernel
 // (A.ovf != null), a step whose contacts do not fit this kernel's slots is abandoned before anything is written and flagged.
-template <int NV, int NB, int RPL, bool HF, int GTM, bool SC, bool PROF, int EPW, int MCT, bool FIX>
-__device__ __forceinline__ void env_body(KArgsP kargs_p, const int env, typename KTraits<NV, NB, RPL, HF, SC, EPW, MCT>::L (&SS)[EPW]) {
+// KM: see KTraits.  wsel: (KM == 1) which of the env's A.nw narrowphase waves this is.
+template <int NV, int NB, int RPL, bool HF, int GTM, bool SC, bool PROF, int EPW, int MCT, bool FIX, int KM = 0>
+__device__ __forceinline__ void env_body(KArgsP kargs_p, const int env, typename KTraits<NV, NB, RPL, HF, SC, EPW, MCT, KM>::L (&SS)[EPW], const int wsel = 0) {
   static_assert(EPW == 1 || (EPW == 2 && !HF && !SC && NV <= 32 && NB <= 32), "two environments per wave: flat ground, no pairs");
   static_assert(MCT == 0 || EPW == 1, "contact-twist mode: one environment per wave");
-  using KT = KTraits<NV, NB, RPL, HF, SC, EPW, MCT>;
+  static_assert(KM == 0 || (HF && MCT > 0 && EPW == 1 && !FIX && (!PROF || KM == 1)), "split pipeline: heightfield contact-twist kernels");
+  using KT = KTraits<NV, NB, RPL, HF, SC, EPW, MCT, KM>;
+  // split pipeline: this launch is substep sub_index of sub_total; the control-step prologue runs in the first, the epilogue in the last
+  const bool sub_first = KM == 0 || A.sub_total == 0 || A.sub_index == 0;
+  const bool sub_last = KM == 0 || A.sub_total == 0 || A.sub_index == A.sub_total - 1;
   constexpr bool CT = MCT > 0;
   constexpr bool NRM = KT::NRM;            // the (ground) contact list stores normals; otherwise they are +z
   constexpr bool NRMD = CT ? true : NRM;   // normals of the contacts behind dense rows (CT: the robot-robot slots always store them)
@@ -601,6 +624,7 @@ __device__ __forceinline__ void env_body(KArgsP kargs_p, const int env, typename
   // diagnostic build only: shader-clock time per phase, summed over the substeps (never executed in the product kernel)
   unsigned long long pt0 = 0, pacc[16], pext[16];   // pext: heightfield narrowphase: cycles in [0] sub-grids [1] probe passes [2] full-MPR batches; counts [3] work items [4] probe batches [5] probes run [6] full batches [7] full MPRs run
   if (PROF) { for (int i = 0; i < 16; i++) pacc[i] = 0; for (int i = 0; i < 16; i++) pext[i] = 0; pt0 = __builtin_amdgcn_s_memtime(); }
+  const unsigned long long pt_wave0 = PROF ? pt0 : 0ull;
 #define PEXT_T0() unsigned long long pe0_ = 0; if (PROF) { __builtin_amdgcn_s_waitcnt(0); pe0_ = __builtin_amdgcn_s_memtime(); }
 #define PEXT_ADD(i) do { if (PROF) { __builtin_amdgcn_s_waitcnt(0); unsigned long long t_ = __builtin_amdgcn_s_memtime(); pext[i] += t_ - pe0_; pe0_ = t_; } } while (0)
 #define STAMP(i) do { KARGS_FENCE(); if (PROF) { __builtin_amdgcn_s_waitcnt(0); unsigned long long t_ = __builtin_amdgcn_s_memtime(); pacc[i] += t_ - pt0; pt0 = t_; } } while (0)
@@ -657,7 +681,16 @@ __device__ __forceinline__ void env_body(KArgsP kargs_p, const int env, typename
     WSYNC();
 
     // ---- control (once per control step): delay filter + PD, zero-order hold over the substeps
-    if (kmode == MODE_STEP) {
+    if constexpr (KM == 2) {
+      if (kmode == MODE_STEP && !sub_first) {   // a later substep launch of the control step: what the first one computed
+        const float* xs = A.xstate + (size_t)env * XS;
+        if (lane < NV) S.qact[lane] = xs[lane];
+        if (lane < nu) { S.act[lane] = xs[NV + lane]; S.tq[lane] = xs[NV + L::NUMAX + lane]; }
+        if (lane < CS_MAXCMD) S.cmd[lane] = xs[NV + 2 * L::NUMAX + lane];   // the applied command is a function of the PRE-step pose
+        WSYNC();
+      }
+    }
+    if (KM != 1 && kmode == MODE_STEP && sub_first) {
       const bool delayed = (ob.action_delay_prob > u01(philox_first(k0, k1, step_count, 0u, g0, g1))) && has_prev;  // control_manager.py:15-23
       if (lane < nu) {
         const auto& R = dm.rec[lane];
@@ -684,7 +717,7 @@ __device__ __forceinline__ void env_body(KArgsP kargs_p, const int env, typename
       WSYNC();
     }
 
-    const int nsub = kmode == MODE_DEBUG ? 1 : (A.nsub_override > 0 ? A.nsub_override : dm.frame_skip);
+    const int nsub = (kmode == MODE_DEBUG || KM != 0) ? 1 : (A.nsub_override > 0 ? A.nsub_override : dm.frame_skip);
 #pragma nounroll
     for (int sub = 0; sub < nsub; sub++) {
       int ln = lane;
@@ -748,8 +781,11 @@ __device__ __forceinline__ void env_body(KArgsP kargs_p, const int env, typename
       }
 
       STAMP(1);   // kinematics
-      // =========================================================== mj_comPos: com, cinert (lane = body)
+      float com[3] = {0.f, 0.f, 0.f};   // the tree's centre of mass
+      float qv = 0.f;                   // this lane's dof velocity at the start of the substep
       float cinert[10];
+      if constexpr (KM != 1) {   // (the narrowphase-only kernel needs the body poses, nothing else)
+      // =========================================================== mj_comPos: com, cinert (lane = body)
 #pragma unroll
       for (int k = 0; k < 10; k++) cinert[k] = 0.f;
       {
@@ -798,10 +834,9 @@ __device__ __forceinline__ void env_body(KArgsP kargs_p, const int env, typename
         }
       }
       WSYNC();
-      const float com[3] = {S.com[0], S.com[1], S.com[2]};
+      com[0] = S.com[0]; com[1] = S.com[1]; com[2] = S.com[2];
       // cdof (lane = dof)
       float cd[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-      float qv = 0.f;
       {
         const auto& R = dm.rec[ln];
         if (ln < NV) {
@@ -951,7 +986,7 @@ __device__ __forceinline__ void env_body(KArgsP kargs_p, const int env, typename
       }
 
       // sensors of this forward pass (framequat, gyro, velocimeter on the IMU site); only the last substep's are read
-      if (sub == nsub - 1) {
+      if (sub == nsub - 1 && sub_last) {
         const int ib = dm.imu_body;
         float xq[4] = {S.xquat[ib][0], S.xquat[ib][1], S.xquat[ib][2], S.xquat[ib][3]};
         float s_quat[4];
@@ -980,6 +1015,7 @@ __device__ __forceinline__ void env_body(KArgsP kargs_p, const int env, typename
         }
       }
 
+      }   // KM != 1
       STAMP(4);   // comVel + rne + sensors
       // =========================================================== collision: ground (plane or heightfield) vs robot geoms
       int ncon = 0;
@@ -987,6 +1023,7 @@ __device__ __forceinline__ void env_body(KArgsP kargs_p, const int env, typename
       const HullGraph HG{A.hull_vert, A.hull_adr, A.hull_nbr};
       const float4* const gext_ = A.gext;   // (locals, so that the lambdas below do not capture the argument-block pointer)
       const float* const hfdata_ = A.hfield;
+      float* const xcon_ = KM == 1 ? A.xcon + (size_t)env * (XG * XC * 8) : nullptr;   // narrowphase kernel: this env's contact records
       // world pose of geom g as a convex object (mesh: body frame, vertices in body coordinates; primitive: geom frame)
       auto make_cobj = [&](CObj& o, int g) __attribute__((always_inline)) {
         const auto& G = dm.rec[g];
@@ -1018,7 +1055,8 @@ __device__ __forceinline__ void env_body(KArgsP kargs_p, const int env, typename
         T.dx = is_plane ? 1.0 : 2.0 * (double)T.sx / (double)(T.ncol - 1); T.dy = is_plane ? 1.0 : 2.0 * (double)T.sy / (double)(T.nrow - 1);
         bool mesh_near = false;
         const float gpos[3] = {0.f, 0.f, T.gz};
-        const bool active = ln < ngeom && R.g_ground;
+        // (narrowphase kernel: wave wsel of the env's A.nw waves takes every A.nw-th geom)
+        const bool active = ln < ngeom && R.g_ground && (KM != 1 || (ln % A.nw) == wsel);
         const int b = active ? R.g_body : 0, gt = active ? R.g_type : -1;
         float xq[4] = {S.xquat[b][0], S.xquat[b][1], S.xquat[b][2], S.xquat[b][3]};
         float xp[3] = {S.xpos[b][0], S.xpos[b][1], S.xpos[b][2]};
@@ -1072,7 +1110,28 @@ __device__ __forceinline__ void env_body(KArgsP kargs_p, const int env, typename
           // supports are O(1), hull supports climb the neighbour graph).  A geom keeps its first mjMAXCONPAIR = 50 penetrating
           // prisms.  The walk is a loop over however many prisms lie under the geoms: 1 cm stairs cells cost passes, not slots.
           static_assert(!HF || CT, "heightfield kernels run in contact-twist mode");
-          if constexpr (CT) {
+          if constexpr (CT && KM == 2) {
+            // split pipeline: the narrowphase kernel has left this substep's contacts in global memory, per geom in strip order
+            // (MuJoCo's order within a geom); geoms in index order make the list
+            const int* xc = A.xcnt + (size_t)env * XG;
+            int end = ln < ngeom ? min(max(xc[ln], 0), XC) : 0;
+#pragma unroll
+            for (int o = 1; o < 32; o <<= 1) { const int t = __shfl_up(end, o, 64); if (ln >= o) end += t; }
+            if (ln < 24) S.hf_end[ln] = end;
+            const int total = __builtin_amdgcn_readlane(end, 23);
+            WSYNC();
+            const float* xb = A.xcon + (size_t)env * (XG * XC * 8);
+            for (int idx = ln; idx < total && idx < MC; idx += 64) {
+              int g = 0;
+              while (idx >= S.hf_end[g]) g++;
+              const float4* r = reinterpret_cast<const float4*>(xb + ((size_t)g * XC + (idx - (g > 0 ? S.hf_end[g > 0 ? g - 1 : 0] : 0))) * 8);
+              const float4 a = r[0], bb = r[1];
+              S.cdist[idx] = a.x; S.cgeom[idx] = g;
+              S.cpos[idx][0] = a.y; S.cpos[idx][1] = a.z; S.cpos[idx][2] = a.w;
+              S.cnrm[NRM ? idx : 0][0] = bb.x; S.cnrm[NRM ? idx : 0][1] = bb.y; S.cnrm[NRM ? idx : 0][2] = bb.z;
+            }
+            ncon = total;
+          } else if constexpr (CT) {
             if (ln == 0) S.ncon_ctr = 0;
             PEXT_T0();
             int n_items = 0;
@@ -1127,6 +1186,24 @@ __device__ __forceinline__ void env_body(KArgsP kargs_p, const int env, typename
                   if (rmax > rmin && ppr > 0) {
                     n_items = (rmax - rmin) * ppr;
                     S.hf_cmin[ln] = cmin; S.hf_rmin[ln] = rmin; S.hf_ppr[ln] = ppr; S.hf_lo[ln] = lo[2]; S.hf_mg[ln] = margin;
+                    if constexpr (KM == 1) {
+                      // oriented box for the per-prism cull of the height pass: primitives in their own frame (box: its size; cylinder:
+                      // (r, r, h); sphere: r), hulls in the body frame (the box of the hull's vertices), each grown by the farthest a
+                      // point of a prism's footprint lies from the footprint's centroid
+                      const float grow = 0.7f * sqrtf((float)(T.dx * T.dx + T.dy * T.dy));
+                      float bm[9], bc[3], bh[3];
+                      if (gt == CS_GEOM_MESH) {
+                        q2m(bm, xq);
+                        for (int k = 0; k < 3; k++) { bc[k] = ctr[k]; bh[k] = R.g_half[k]; }
+                      } else {
+                        q2m(bm, og.q);
+                        for (int k = 0; k < 3; k++) bc[k] = og.pos[k];
+                        bh[0] = og.size[0]; bh[1] = gt == CS_GEOM_BOX ? og.size[1] : og.size[0];
+                        bh[2] = gt == CS_GEOM_BOX ? og.size[2] : (gt == CS_GEOM_CYLINDER ? og.size[1] : og.size[0]);
+                      }
+                      for (int k = 0; k < 3; k++) { S.hf_box[ln][k] = bc[k]; S.hf_box[ln][12 + k] = bh[k] + grow; }
+                      for (int k = 0; k < 9; k++) S.hf_box[ln][3 + k] = bm[k];
+                    }
                     // a hull with only a few prisms under it (coarse terrain): its prisms one at a time with all 64 lanes sharing the
                     // vertex scans -- 64 lanes each scanning a 700-vertex hull for a handful of items would cost more
                     if (gt == CS_GEOM_MESH && n_items < 32 && R.g_hullnum > 64) { coop_geom = true; n_items = 0; }
@@ -1207,7 +1284,13 @@ __device__ __forceinline__ void env_body(KArgsP kargs_p, const int env, typename
               const bool keep = hit && S.hf_cnt[g] + rank_g < 50;
               const unsigned long long km = __ballot(keep);
               const int slot = S.ncon_ctr + __popcll(km & lanemask_lt(ln));
-              if (keep && slot < MC) {
+              if constexpr (KM == 1) {   // to the env's record in global memory: slot (geom, rank among the geom's hits)
+                if (keep) {
+                  float4* o = reinterpret_cast<float4*>(xcon_ + ((size_t)g * XC + S.hf_cnt[g] + rank_g) * 8);
+                  o[0] = make_float4(gmargin - depth, pos_[0], pos_[1], pos_[2]);
+                  o[1] = make_float4(nrm_[0], nrm_[1], nrm_[2], 0.f);
+                }
+              } else if (keep && slot < MC) {
                 S.cdist[slot] = gmargin - depth;
                 S.cgeom[slot] = g;
                 for (int k = 0; k < 3; k++) { S.cpos[slot][k] = pos_[k]; S.cnrm[NRM ? slot : 0][k] = nrm_[k]; }
@@ -1279,11 +1362,13 @@ __device__ __forceinline__ void env_body(KArgsP kargs_p, const int env, typename
                   constexpr int HB = L::HFB;
                   bool alive[HB];
                   float hv[HB][3], lo2[HB], add[HB];
+                  float cxy[HB][2];   // narrowphase kernel: centroid of the prism's footprint
+                  int gsel[HB];
 #pragma unroll
                   for (int j = 0; j < HB; j++) {
                     const int item = base + ln + 64 * j;
                     alive[j] = false;
-                    lo2[j] = 0.f; add[j] = 0.f;
+                    lo2[j] = 0.f; add[j] = 0.f; cxy[j][0] = cxy[j][1] = 0.f; gsel[j] = 0;
                     int idx[3] = {0, 0, 0};
                     if (item < total) {
                       int g = g0;
@@ -1291,10 +1376,17 @@ __device__ __forceinline__ void env_body(KArgsP kargs_p, const int env, typename
                       const int k = item - (g > 0 ? S.hf_end[g > 0 ? g - 1 : 0] : 0), ppr = S.hf_ppr[g], rrow = k / ppr, kk = k - rrow * ppr;
                       const int r = S.hf_rmin[g] + rrow, cmin = S.hf_cmin[g];
                       lo2[j] = S.hf_lo[g]; add[j] = T.gz + S.hf_mg[g];
+                      int csum = 0, rsum = 0;
 #pragma unroll
                       for (int i = 0; i < 3; i++) {
                         const int v = kk + i, c = cmin + (v >> 1), rr = r + 1 - (v & 1);
                         idx[i] = rr * T.ncol + c;
+                        csum += c; rsum += rr;
+                      }
+                      if constexpr (KM == 1) {
+                        gsel[j] = g;
+                        cxy[j][0] = (float)((double)csum * (1.0 / 3.0) * T.dx - (double)T.sx - T.ox);
+                        cxy[j][1] = (float)((double)rsum * (1.0 / 3.0) * T.dy - (double)T.sy - T.oy);
                       }
                       alive[j] = S.hf_cnt[g] < 50;
                     }
@@ -1313,6 +1405,32 @@ __device__ __forceinline__ void env_body(KArgsP kargs_p, const int env, typename
                     bool below = true;
 #pragma unroll
                     for (int i = 0; i < 3; i++) below = below && (hv[j][i] * T.sz + add[j] < lo2[j]);
+                    if constexpr (KM == 1) {
+                      // A prism that touches the geom holds a point p of the geom's box whose (x, y) lies in the prism's footprint, i.e.
+                      // within `grow` of the footprint's centroid c: (c.x, c.y, p.z) then lies in the GROWN box, so the vertical line
+                      // through c meets the grown box, and no lower than it enters it can p be.  Line misses the box, or enters it above
+                      // the prism's (margin-raised) top: the prism cannot touch.  This is what thins out the walk of a long limb lying
+                      // askew (its footprint is a sliver of its axis-aligned sub-grid) or tilted (one end high above the steps).
+                      if (alive[j] && !below) {
+                        const float* B = S.hf_box[gsel[j]];
+                        const float rx = cxy[j][0] - B[0], ry = cxy[j][1] - B[1], rz = -B[2];   // line origin (c.x, c.y, 0) relative to the box centre
+                        float t0 = -3.0e38f, t1 = 3.0e38f;
+                        bool miss = false;
+#pragma unroll
+                        for (int k = 0; k < 3; k++) {
+                          const float o_ = B[3 + k] * rx + B[6 + k] * ry + B[9 + k] * rz;   // R^T (origin - centre), component k
+                          const float d_ = B[9 + k];                                           // R^T e_z, component k
+                          const float hk = B[12 + k];
+                          if (fabsf(d_) < 1e-6f) miss = miss || fabsf(o_) > hk;
+                          else {
+                            const float inv = 1.f / d_, ta = (-hk - o_) * inv, tb = (hk - o_) * inv;
+                            t0 = fmaxf(t0, fminf(ta, tb)); t1 = fminf(t1, fmaxf(ta, tb));
+                          }
+                        }
+                        const float ztop = fmaxf(hv[j][0], fmaxf(hv[j][1], hv[j][2])) * T.sz + add[j];
+                        if (miss || t0 > t1 || t0 > ztop + 1e-5f) below = true;
+                      }
+                    }
                     const bool al = alive[j] && !below;
                     const unsigned long long am = __ballot(al);
                     if (al) S.hf_zlist[nz + __popcll(am & lanemask_lt(ln))] = base + ln + 64 * j;
@@ -1339,14 +1457,40 @@ __device__ __forceinline__ void env_body(KArgsP kargs_p, const int env, typename
                 qrot(v, gq, G.g_rcenter);
                 for (int k = 0; k < 3; k++) gctr[k] = S.xpos[G.g_body][k] + v[k];
               }
+              int cg = 0;   // narrowphase kernel: hits of this geom so far
               hfield_geom<GTM, true>(T, o, gctr, G.g_rbound, G.g_margin, dm.hfield_size[3], HG, ln, [&](float dist, const float* pos, const float* n) {
-                if (ncon < MC && ln == 0) {
-                  S.cdist[ncon] = dist;
-                  S.cgeom[ncon] = g;
-                  for (int k = 0; k < 3; k++) { S.cpos[ncon][k] = pos[k]; S.cnrm[NRM ? ncon : 0][k] = n[k]; }
+                if constexpr (KM == 1) {
+                  if (ln == 0 && cg < XC) {
+                    float4* oo = reinterpret_cast<float4*>(xcon_ + ((size_t)g * XC + cg) * 8);
+                    oo[0] = make_float4(dist, pos[0], pos[1], pos[2]);
+                    oo[1] = make_float4(n[0], n[1], n[2], 0.f);
+                  }
+                  cg++;
+                } else {
+                  if (ncon < MC && ln == 0) {
+                    S.cdist[ncon] = dist;
+                    S.cgeom[ncon] = g;
+                    for (int k = 0; k < 3; k++) { S.cpos[ncon][k] = pos[k]; S.cnrm[NRM ? ncon : 0][k] = n[k]; }
+                  }
+                  ncon++;
                 }
-                ncon++;
               }, PROF ? pext + 8 : nullptr);   // heightfield kernels: [24..29] = cooperative walk: box cycles, MPR runs, MPR cycles, geoms, hits, refinement iterations
+              if constexpr (KM == 1) { if (ln == 0) S.hf_cnt[g] = min(cg, XC); }
+            }
+            if constexpr (KM == 1) {
+              // the narrowphase kernel ends here: contacts found per owned geom (every launch overwrites them), counters, done
+              WSYNC();
+              if (active) A.xcnt[(size_t)env * XG + ln] = S.hf_cnt[ln];
+              if (ln == 0 && st_walkcut > 0) { atomicAdd(&meta[8], st_walkcut); atomicAdd(&meta[13], st_walkcut); }
+              if (PROF && A.dbg != nullptr && ln == 0) {   // diagnostic build: wave lifetime (sum, max, count), the walk's phases, items / batches
+                unsigned long long* D = reinterpret_cast<unsigned long long*>(A.dbg);
+                const unsigned long long life = __builtin_amdgcn_s_memtime() - pt_wave0;
+                atomicAdd(D + 0, life); atomicMax(D + 1, life); atomicAdd(D + 2, 1ull);
+                atomicAdd(D + 3, (unsigned long long)total);          // work items of this wave's geoms
+                for (int i = 0; i < 8; i++) atomicAdd(D + 8 + i, pext[i]);
+                if (life > 400000ull) { atomicAdd(D + 4, 1ull); atomicAdd(D + 5, (unsigned long long)total); atomicAdd(D + 6, pext[0]); atomicAdd(D + 7, pext[1] + pext[2]); }
+              }
+              return;
             }
           }
         }
@@ -2339,7 +2483,7 @@ __device__ __forceinline__ void env_body(KArgsP kargs_p, const int env, typename
       // =========================================================== _is_done of flamingo_p_v3 (flamingo_p_v3.py:225-233)
       // cfrc_ext of mj_rnePostConstraint for the listed bodies: sum of contact wrenches [torque; force], world aligned,
       // about the tree's CoM; "any signed component > 1.0" terminates.  Uses the last substep's contacts and forces.
-      if (dm.term_mode == 1 && sub == nsub - 1) {
+      if (dm.term_mode == 1 && sub == nsub - 1 && sub_last) {
         bool hit = false;
         if (ln > 0 && ln < nbody && ((dm.term_bodymask >> ln) & 1u)) {
           float wr[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -2425,6 +2569,26 @@ __device__ __forceinline__ void env_body(KArgsP kargs_p, const int env, typename
       STAMP(8);   // implicitfast + advance
     }  // substeps
     if (kmode == MODE_DEBUG) return;
+    if constexpr (KM == 2) {
+      if (kmode == MODE_STEP && !sub_last) {
+        // split pipeline, not the control step's last substep: the physics state goes back to the record (the next narrowphase launch
+        // reads the new pose), the control step's own values wait in xstate, the counters accumulate; no epilogue yet
+        if (lane < nq) rec[lay.s_qpos + lane] = S.qpos[lane];
+        if (lane < NV) { rec[lay.s_qvel + lane] = S.qvel[lane]; rec[lay.s_warm + lane] = S.qacc[lane]; }
+        if (sub_first) {
+          float* xs = A.xstate + (size_t)env * XS;
+          if (lane < NV) xs[lane] = S.qact[lane];
+          if (lane < nu) { xs[NV + lane] = S.act[lane]; xs[NV + L::NUMAX + lane] = S.tq[lane]; }
+          if (lane < CS_MAXCMD) xs[NV + 2 * L::NUMAX + lane] = S.cmd[lane];
+        }
+        if (lane == 0) {
+          meta[0] = sim_step; meta[2] = has_prev;
+          meta[5] += st_newton; meta[6] += st_ls; meta[7] += st_build; meta[3] += st_rows;
+          meta[8] += st_dropcon + st_walkcut; meta[9] += st_droplim; meta[10] = max(meta[10], st_maxcon); meta[13] += st_walkcut;
+        }
+        return;
+      }
+    }
 
     // ---- mj_checkPos/Vel: non-finite state -> this env is reset (MuJoCo resets the data and warns)
     {
@@ -2614,6 +2778,34 @@ __global__ __launch_bounds__(64, (EPW == 2 ? 2 : waves_per_simd(163840 / (int)si
   const int env = A.mode == MODE_DEBUG ? A.dbg_env : A.env_first + (int)blockIdx.x * EPW + (EPW == 1 ? 0 : ((int)threadIdx.x >> 5));
   if (env >= A.n_envs) return;
   env_body<NV, NB, RPL, HF, GTM, SC, PROF, EPW, MCT, false>(kargs_p, env, SS);
+}
+
+// Split pipeline (heightfield kernels whose narrowphase dwarfs everything else: humanoid_p_v0 on 1 cm stairs cells spends 89 % of a
+// fused control step in the prism walk, at one wave per SIMD -- 39 KB of LDS and 278 registers per env -- so every dependent load and
+// fp64 portal operation is fully exposed, and a launch lasts as long as its slowest, fallen, env).  Per substep two launches:
+//   env_narrow_kernel: kinematics + the prism walk only, A.nw waves per env (wave w takes the geoms g % nw == w: a standing robot's
+//     two feet walk side by side, a fallen one's twenty geoms spread over all waves), slim LDS and registers -> several waves per
+//     SIMD; contacts go to an L2-resident record per (env, geom), in MuJoCo's strip order;
+//   env_step_kernel: the solver kernel, one substep, ground contacts read from that record (robot-robot pairs stay here).
+// OCC: waves per SIMD the register allocator is asked for (4: 128 registers, the fp64 portal of MPR spills ~150 of them; 2: 256, none)
+template <int NV, int NB, int RPL, bool HF, int GTM, bool SC, int MCT, int OCC, bool PROF = false>
+__global__ __launch_bounds__(64, OCC) void env_narrow_kernel(KArgs kernarg_block) {
+  KArgsP kargs_p = (KArgsP)__builtin_amdgcn_kernarg_segment_ptr();
+  (void)kernarg_block;
+  __shared__ typename KTraits<NV, NB, RPL, HF, SC, 1, MCT, 1>::L SS[1];
+  const int nw = A.nw;
+  const int env = A.mode == MODE_DEBUG ? A.dbg_env : A.env_first + (int)blockIdx.x / nw;
+  if (env >= A.n_envs) return;
+  env_body<NV, NB, RPL, HF, GTM, SC, PROF, 1, MCT, false, 1>(kargs_p, env, SS, (int)blockIdx.x % nw);
+}
+template <int NV, int NB, int RPL, bool HF, int GTM, bool SC, int MCT>
+__global__ __launch_bounds__(64, waves_per_simd(163840 / (int)sizeof(typename KTraits<NV, NB, RPL, HF, SC, 1, MCT, 2>::L))) void env_step_kernel(KArgs kernarg_block) {
+  KArgsP kargs_p = (KArgsP)__builtin_amdgcn_kernarg_segment_ptr();
+  (void)kernarg_block;
+  __shared__ typename KTraits<NV, NB, RPL, HF, SC, 1, MCT, 2>::L SS[1];
+  const int env = A.mode == MODE_DEBUG ? A.dbg_env : A.env_first + (int)blockIdx.x;
+  if (env >= A.n_envs) return;
+  env_body<NV, NB, RPL, HF, GTM, SC, false, 1, MCT, false, 2>(kargs_p, env, SS);
 }
 
 // The large-capacity kernel behind a fleet kernel whose contact slots can run out (flamingo_light_v1 on the plane: 14 dense

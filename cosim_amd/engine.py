@@ -103,7 +103,7 @@ def load_library():
     L.cosim_profile_step.argtypes = [vp] * 7
     L.cosim_last_error.restype = ctypes.c_char_p
     for fn in ("cosim_create", "cosim_destroy", "cosim_query", "cosim_set_param", "cosim_reset", "cosim_step", "cosim_step_range", "cosim_get",
-               "cosim_join", "cosim_range", "cosim_range_mark",
+               "cosim_join", "cosim_range", "cosim_range_mark", "cosim_debug_counters",
                "cosim_set", "cosim_event_push", "cosim_debug_forward", "cosim_kernel_time", "cosim_set_timing",
                "cosim_profile_step", "cosim_model_sizeof", "cosim_obs_config_sizeof"):
         getattr(L, fn).restype = ci
@@ -269,6 +269,13 @@ class Engine:
     def profile_step(self, actions_ptr, commands_ptr, state_out_ptr, term_ptr, trunc_ptr) -> np.ndarray:
         out = np.zeros(32, dtype=np.float64)
         self._check(self.L.cosim_profile_step(self.h, actions_ptr, commands_ptr, state_out_ptr, term_ptr, trunc_ptr, out.ctypes.data))
+        return out
+
+    def debug_counters(self, clear: bool = True) -> np.ndarray:
+        out = np.zeros(32, dtype=np.uint64)
+        self.L.cosim_debug_counters.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
+        self.L.cosim_debug_counters.restype = ctypes.c_int
+        self._check(self.L.cosim_debug_counters(self.h, out.ctypes.data, int(clear)))
         return out
 
     def set_timing(self, enabled: bool):

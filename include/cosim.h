@@ -89,7 +89,9 @@ int cosim_query(const cosim_engine_t* e, const char* name);
  * twist space, 32 slots instead of the dense-row kernel's 14, at ~70 % of the speed; before the first step), "ls_tolerance_scale"
  * (multiplies the line-search tolerance; 1 = the model's), "ranges" (1..16: cosim_step issues the fleet as that many launches over
  * contiguous env ranges on engine-owned streams; default 1), "deferred_join" (see cosim_step / cosim_join), "inflight" (control steps cosim_step lets the host run ahead of each
- * range stream before it blocks, default 4, 0 = unbounded: deep queues step slower on this runtime), "fixup" (0 switches the
+ * range stream before it blocks, default 4, 0 = unbounded: deep queues step slower on this runtime), "split" (heightfield kernels that have the two-kernel pipeline -- humanoid_p_v0:
+ * the prism walk in a kernel of its own, "narrow_waves" (default 4) waves per env, and the solver one substep per launch; 0 goes back
+ * to the fused kernel), "fixup" (0 switches the
  * large-capacity fix-up launches off: contacts beyond the fleet kernel's slots are then left out and counted).
  * cosim_query additionally answers "contact_slots" / "pair_slots" (capacity of the selected kernel variant: heightfields with cells
  * of 10 cm or more select the 48-slot variants of flamingo_light_v1 / w4_p_v2), "fixup_contact_slots" (capacity of the kernel that
@@ -146,6 +148,10 @@ int cosim_debug_forward(cosim_engine_t* e, int env, const char* name, float* hos
 
 /* Average duration (ms) of the step kernel since the last call, measured with HIP events on the launch stream, and
  * the number of launches averaged; resets the accumulator. */
+/* Diagnostics: the 32 64-bit counters diagnostic kernel builds accumulate (cosim_set_param "narrow_occupancy" 0: the narrowphase
+ * kernel of the split pipeline -- [0] sum, [1] max, [2] number of wave lifetimes in shader-clock cycles, [3] work items, [8..15]
+ * the walk's phases; see tools/gpu_narrow_prof.py); clear != 0 zeroes them afterwards. */
+int cosim_debug_counters(cosim_engine_t* e, unsigned long long* out32, int clear);
 int cosim_kernel_time(cosim_engine_t* e, float* avg_ms, int* launches);
 int cosim_set_timing(cosim_engine_t* e, int enabled);
 /* Diagnostic build of the step kernel with s_memtime stamps at phase boundaries (one variant per bench workload): one control
