@@ -116,7 +116,7 @@ def load_library():
 
 
 EXPORTS = ["cosim_create", "cosim_destroy", "cosim_query", "cosim_set_param", "cosim_reset", "cosim_step", "cosim_step_range", "cosim_get",
-           "cosim_join", "cosim_range", "cosim_range_mark",
+           "cosim_join", "cosim_range", "cosim_range_mark", "cosim_debug_counters",
            "cosim_set", "cosim_event_push", "cosim_debug_forward", "cosim_kernel_time", "cosim_set_timing",
            "cosim_profile_step", "cosim_mlp_forward", "cosim_lstm_cell", "cosim_fleet_stats", "cosim_fleet_hist", "cosim_last_error", "cosim_model_sizeof", "cosim_obs_config_sizeof"]
 
