@@ -126,6 +126,13 @@ __device__ __forceinline__ float wave_min(float v) {
   v = fminf(v, dpp<0x140>(v));
   return fminf(fminf(rl(v, 0), rl(v, 16)), fminf(rl(v, 32), rl(v, 48)));
 }
+// k / d for 0 <= k < 2^22, 0 < d < 2^22: one reciprocal and a fix-up instead of the ~35-instruction integer division sequence
+__device__ __forceinline__ int small_div(int k, int d) {
+  int q = (int)((float)k * __builtin_amdgcn_rcpf((float)d));
+  q -= (q * d > k) ? 1 : 0;
+  q += ((q + 1) * d <= k) ? 1 : 0;
+  return q;
+}
 __device__ __forceinline__ unsigned long long lanemask_lt(int lane) { return (1ull << lane) - 1ull; }
 // The same operations over a group of LW lanes = one environment (LW = 64: the whole wave; LW = 32: two environments per
 // wave, lanes 0-31 and 32-63).  hb = first lane of the caller's group.
@@ -277,6 +284,7 @@ struct CtLds {
   // narrowphase kernel: per geom an oriented box around it, grown by the reach of a prism's footprint from its centroid: centre[3],
   // rotation (row-major, local -> world)[9], half extents[3]
   float hf_box[(HF && SLIM) ? 24 : 1][16];
+  float hf_org[(HF && SLIM) ? 24 : 1][2];   // local (x, y) of the sub-grid's first vertex (column cmin, row rmin)
 };
 template <bool HF, int NB, int MC, int MCP, bool SLIM>
 struct CtLds<false, HF, NB, MC, MCP, SLIM> {};
@@ -1055,8 +1063,9 @@ __device__ __forceinline__ void env_body(KArgsP kargs_p, const int env, typename
         T.dx = is_plane ? 1.0 : 2.0 * (double)T.sx / (double)(T.ncol - 1); T.dy = is_plane ? 1.0 : 2.0 * (double)T.sy / (double)(T.nrow - 1);
         bool mesh_near = false;
         const float gpos[3] = {0.f, 0.f, T.gz};
-        // (narrowphase kernel: wave wsel of the env's A.nw waves takes every A.nw-th geom)
-        const bool active = ln < ngeom && R.g_ground && (KM != 1 || (ln % A.nw) == wsel);
+        // (narrowphase kernel: every wave of the env sizes every geom's walk -- lane-parallel, cheap -- and then takes its share of the
+        // geoms by work, see `mine` below)
+        const bool active = ln < ngeom && R.g_ground;
         const int b = active ? R.g_body : 0, gt = active ? R.g_type : -1;
         float xq[4] = {S.xquat[b][0], S.xquat[b][1], S.xquat[b][2], S.xquat[b][3]};
         float xp[3] = {S.xpos[b][0], S.xpos[b][1], S.xpos[b][2]};
@@ -1187,6 +1196,8 @@ __device__ __forceinline__ void env_body(KArgsP kargs_p, const int env, typename
                     n_items = (rmax - rmin) * ppr;
                     S.hf_cmin[ln] = cmin; S.hf_rmin[ln] = rmin; S.hf_ppr[ln] = ppr; S.hf_lo[ln] = lo[2]; S.hf_mg[ln] = margin;
                     if constexpr (KM == 1) {
+                      S.hf_org[ln][0] = (float)((double)cmin * T.dx - (double)T.sx - T.ox);
+                      S.hf_org[ln][1] = (float)((double)rmin * T.dy - (double)T.sy - T.oy);
                       // oriented box for the per-prism cull of the height pass: primitives in their own frame (box: its size; cylinder:
                       // (r, r, h); sphere: r), hulls in the body frame (the box of the hull's vertices), each grown by the farthest a
                       // point of a prism's footprint lies from the footprint's centroid
@@ -1211,6 +1222,21 @@ __device__ __forceinline__ void env_body(KArgsP kargs_p, const int env, typename
                 }
               }
             }
+            bool mine = active;
+            if constexpr (KM == 1) {
+              // Which of the env's A.nw waves walks which geom: geoms ranked by the size of their walk (work items; a cooperative hull
+              // walk counts as one batch), dealt to the waves in serpentine order -- the biggest walks land on different waves and the
+              // waves' totals stay close.  Every wave of the env computes the same ranking from the same poses.
+              const int work = coop_geom ? 64 : n_items;
+              int rank = 0;
+              for (int g = 0; g < 24; g++) {
+                const int wg = __builtin_amdgcn_readlane(work, g);
+                rank += (wg > work || (wg == work && g < ln)) ? 1 : 0;
+              }
+              const int nw_ = A.nw, round_ = rank / nw_, pos_ = rank - round_ * nw_;
+              mine = active && ((round_ & 1) ? nw_ - 1 - pos_ : pos_) == wsel;
+              if (!mine) { n_items = 0; coop_geom = false; walk_cut = false; }
+            }
             st_walkcut += __popcll(__ballot(walk_cut));   // wave-uniform (lane 0 writes the counters back): one per geom whose walk was cut short
             int end = n_items;   // inclusive prefix sum over the geom lanes
 #pragma unroll
@@ -1224,7 +1250,7 @@ __device__ __forceinline__ void env_body(KArgsP kargs_p, const int env, typename
             // sits in column cmin + (v >> 1), row r + 1 for even v and r for odd v)
             auto item_prism = [&](int item, int& g, float& gmargin, PrismObj& P) __attribute__((always_inline)) {
               while (item >= S.hf_end[g]) g++;
-              const int k = item - (g > 0 ? S.hf_end[g > 0 ? g - 1 : 0] : 0), ppr = S.hf_ppr[g], rrow = k / ppr, kk = k - rrow * ppr;
+              const int k = item - (g > 0 ? S.hf_end[g > 0 ? g - 1 : 0] : 0), ppr = S.hf_ppr[g], rrow = small_div(k, ppr), kk = k - rrow * ppr;
               const int r = S.hf_rmin[g] + rrow, cmin = S.hf_cmin[g];
               gmargin = S.hf_mg[g];
               P.zb = T.gz - dm.hfield_size[3];
@@ -1373,7 +1399,7 @@ __device__ __forceinline__ void env_body(KArgsP kargs_p, const int env, typename
                     if (item < total) {
                       int g = g0;
                       while (item >= S.hf_end[g]) g++;
-                      const int k = item - (g > 0 ? S.hf_end[g > 0 ? g - 1 : 0] : 0), ppr = S.hf_ppr[g], rrow = k / ppr, kk = k - rrow * ppr;
+                      const int k = item - (g > 0 ? S.hf_end[g > 0 ? g - 1 : 0] : 0), ppr = S.hf_ppr[g], rrow = small_div(k, ppr), kk = k - rrow * ppr;
                       const int r = S.hf_rmin[g] + rrow, cmin = S.hf_cmin[g];
                       lo2[j] = S.hf_lo[g]; add[j] = T.gz + S.hf_mg[g];
                       int csum = 0, rsum = 0;
@@ -1384,9 +1410,11 @@ __device__ __forceinline__ void env_body(KArgsP kargs_p, const int env, typename
                         csum += c; rsum += rr;
                       }
                       if constexpr (KM == 1) {
+                        // centroid of the footprint, relative to the sub-grid's first vertex (fp32 is ample: the box is grown by 0.7 cell
+                        // diagonals where 0.67 would do, and a sub-grid is at most a few metres wide)
                         gsel[j] = g;
-                        cxy[j][0] = (float)((double)csum * (1.0 / 3.0) * T.dx - (double)T.sx - T.ox);
-                        cxy[j][1] = (float)((double)rsum * (1.0 / 3.0) * T.dy - (double)T.sy - T.oy);
+                        cxy[j][0] = S.hf_org[g][0] + (float)(csum - 3 * cmin) * (1.f / 3.f) * (float)T.dx;
+                        cxy[j][1] = S.hf_org[g][1] + (float)(rsum - 3 * S.hf_rmin[g]) * (1.f / 3.f) * (float)T.dy;
                       }
                       alive[j] = S.hf_cnt[g] < 50;
                     }
@@ -1480,7 +1508,7 @@ __device__ __forceinline__ void env_body(KArgsP kargs_p, const int env, typename
             if constexpr (KM == 1) {
               // the narrowphase kernel ends here: contacts found per owned geom (every launch overwrites them), counters, done
               WSYNC();
-              if (active) A.xcnt[(size_t)env * XG + ln] = S.hf_cnt[ln];
+              if (mine) A.xcnt[(size_t)env * XG + ln] = S.hf_cnt[ln];
               if (ln == 0 && st_walkcut > 0) { atomicAdd(&meta[8], st_walkcut); atomicAdd(&meta[13], st_walkcut); }
               if (PROF && A.dbg != nullptr && ln == 0) {   // diagnostic build: wave lifetime (sum, max, count), the walk's phases, items / batches
                 unsigned long long* D = reinterpret_cast<unsigned long long*>(A.dbg);
