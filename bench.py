@@ -195,8 +195,12 @@ def pmc_traffic(workload):
     files.sort(key=lambda f: [int(x) for x in re.findall(r"\d+", os.path.basename(f))])
     if not files:
         return {"traffic": None}
-    vals, valu = {}, None
+    vals, valu, sections = {}, None, 0
     for line in open(files[-1]):
+        if line.startswith("per launch of"):
+            sections += 1
+            if sections > 1:
+                break                                                # first section = the kernel with the most GPU time
         t = line.split()
         if len(t) >= 3 and t[0] in ("FETCH_SIZE", "WRITE_SIZE"):
             vals[t[0]] = float(t[2]) * 1024.0                        # rocprofv3 reports both in KiB

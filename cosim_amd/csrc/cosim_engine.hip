@@ -568,7 +568,21 @@ int cosim_create(const cosim_model_t* model, const float* hull_vert, const int* 
     // frictionloss rows and at most 8 limit rows (8 hinges)
     // (no coarse-cell variant: at one row per lane the 64-slot kernel already fits the 12 waves per CU its registers allow)
     select_t<14, 10, 1, G_MESH, true, 32, 64, 64>(e, hf, coarse);
-    if (!hf) e->launch_prof = launch_prof_t<14, 10, 1, false, G_MESH, true, 32>;
+    if (!hf) {
+      // Plane: dense rows, like flamingo_light_v1.  With the friction-loss and limit rows in their dofs' lanes all 64 slots are contact
+      // rows: 16 contacts, ground and robot-robot together (most seen in the bench: 16), and the dense solver iteration is cheaper
+      // than the contact-twist one at these counts (kernel 0.325 ms against 0.400 per 1024 envs).  A control step with more is redone
+      // by the contact-twist kernel (32 ground slots = four per geom, the narrowphase's maximum, + 8 pair slots) right behind it;
+      // cosim_set_param "contact_twist" 1 makes that kernel the fleet kernel, as in round 2.
+      e->launch_ct = e->launch; e->launch_ct_prof = launch_prof_t<14, 10, 1, false, G_MESH, true, 32>;
+      e->ct_lds_bytes = e->lds_bytes; e->ct_contact_slots = e->contact_slots;
+      using LD_ = typename KTraits<14, 10, 1, false, true, 1, 0>::L;
+      e->launch = launch_t<14, 10, 1, false, G_MESH, true, 0>;
+      e->launch_prof = launch_prof_t<14, 10, 1, false, G_MESH, true, 0>;
+      e->lds_bytes = (int)sizeof(LD_); e->contact_slots = LD_::MC; e->pair_slots = 0;
+      e->launch_fix = launch_fix_t<14, 10, 1, false, G_MESH, true, 32>;
+      e->fix_contact_slots = 32;
+    }
   }
   else if (nv == 22 && nb <= 18 && (gtm & ~G_MESH) == 0) {   // w4_p_v2
     // plane: at most 4 contacts per geom (17 geoms); 80 slots keep the env at 19 KB of LDS = the 8 waves per CU its 256 registers allow
@@ -587,6 +601,7 @@ int cosim_create(const cosim_model_t* model, const float* hull_vert, const int* 
     }
   }
   else { delete e; return fail(COSIM_EINVAL, "cosim_create: no kernel instantiation for this (nv, nbody); add one in cosim_engine.hip"); }
+  if (nv != 18 && model->neq > 0) { delete e; return fail(COSIM_EINVAL, "cosim_create: this robot's kernels keep no rows for connect equalities"); }
   if (model->ngeom > e->geom_stage) { delete e; return fail(COSIM_EINVAL, "cosim_create: more collision geoms than the plane kernel stages contacts for"); }
   HIP_TRY(hipMalloc(&e->d_model, sizeof(DevModel)));
   HIP_TRY(hipMalloc(&e->d_obs, sizeof(DevObs)));
@@ -737,6 +752,7 @@ int cosim_set_param(cosim_engine_t* e, const char* name, const float* host, int 
       if (!e->launch_ct) return fail(COSIM_EINVAL, "cosim_set_param: no contact-twist variant for this model / terrain");
       e->launch = e->launch_ct; e->launch_prof = e->launch_ct_prof; e->launch2 = nullptr; e->launch_prof2 = nullptr; e->epw = 1;
       e->launch_fix = nullptr;
+      if (e->model.nv == 14) e->pair_slots = 8;
       e->lds_bytes = e->ct_lds_bytes; e->contact_slots = e->ct_contact_slots;
     }
     return COSIM_OK;

@@ -295,7 +295,9 @@ struct EnvLds : CtLds<(MCT > 0), HFL, NB, (MCT > 0 ? MCT : 1), (MCPT > 0 ? MCPT 
   static constexpr bool CT = MCT > 0;
   static constexpr int LD = NV | 1;   // odd leading dimension: conflict-free column access
   static constexpr int ROWS = LW * RPL;            // constraint rows per env: RPL rows per lane, LW lanes per env
-  static constexpr int NEQR = (CT && MCPT > 0) ? 0 : 3 * MAXEQ / 2;   // rows kept for connect equalities (no cosim robot has both equalities and robot-robot pairs; a model that did would trade pair slots for them)
+  // rows kept for connect equalities: flamingo_light_v1 (nv 18) is the only cosim robot that has any (two connects, six rows);
+  // cosim_create refuses a model with equalities on the other robots' kernels
+  static constexpr int NEQR = NV == 18 ? 3 * MAXEQ / 2 : 0;
   // dense rows (one per lane slot) are the connect equalities and the contacts only: friction-loss and limit rows have unit Jacobians
   // (+-e_dof) and live in the lane of their dof ("dof rows", no slot).  64 slots = 6 equality rows + 14 contacts for flamingo_light_v1:
   // every ground contact a fallen robot makes on the plane in the bench (most seen: 14)

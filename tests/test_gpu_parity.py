@@ -1235,7 +1235,9 @@ def test_full_size_fleets_of_the_other_configs_are_sharding_invariant(env_id, te
     assert bool(torch.isfinite(sf).all()) and st["nan_resets"] == 0
     assert float(sf.std(dim=0).max()) > 1e-3 and st["newton_iters"] > n * steps * 4
     if env_id != "humanoid_p_v0":
-        assert st["dropped_contacts"] == 0 and st["max_contacts"] <= int(fleet.engine.query("contact_slots"))
+        # (flamingo_p_v3 on the plane: 16 dense slots, the contact-twist kernel behind them for the rare step with more)
+        assert st["dropped_contacts"] == 0
+        assert st["max_contacts"] <= max(int(fleet.engine.query("contact_slots")), int(fleet.engine.query("fixup_contact_slots")) + 8)
     fleet.close(); shard.close()
 
 

@@ -4,7 +4,7 @@
 # Writes gpurun_out/prof_<tag>_<workload>/{kernel_stats.csv,kernel_trace_summary.txt,pmc_summary.txt}; copy what is to be judged
 # into profiles/.
 set -u
-TAG=${1:-r02}
+TAG=${1:-r03}
 WL=${2:-light_flat}
 STEPS=${3:-40}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_${TAG}_${WL}
@@ -38,15 +38,27 @@ with open(out + "/kernel_trace_summary.txt", "w") as o:
         o.write(f"{k[:110]:110s} {len(v):6d} {sum(v)/len(v)/1e3:10.2f} {min(v)/1e3:10.2f} {max(v)/1e3:10.2f} {sum(v)/1e6:10.3f}\n")
 for f in glob.glob(out + "/trace/*/*kernel_stats.csv"):
     os.replace(f, out + "/kernel_stats.csv")
-tot = collections.defaultdict(float); cnt = collections.defaultdict(int)
+def family(name):
+    for f in ("env_narrow_kernel", "env_step_kernel", "env_fixup_kernel", "env_kernel"):
+        if f in name:
+            return f
+    return None
+tot = collections.defaultdict(lambda: collections.defaultdict(float)); cnt = collections.defaultdict(lambda: collections.defaultdict(int))
 for f in glob.glob(out + "/pass*/*/*counter_collection.csv"):
     for r in csv.DictReader(open(f)):
-        if "env_kernel" in r["Kernel_Name"]:
-            tot[r["Counter_Name"]] += float(r["Counter_Value"]); cnt[r["Counter_Name"]] += 1
+        fam = family(r["Kernel_Name"])
+        if fam:
+            tot[fam][r["Counter_Name"]] += float(r["Counter_Value"]); cnt[fam][r["Counter_Name"]] += 1
+# the kernel with the most GPU time first (bench.py reads the first section as the dominant kernel)
+dur = collections.defaultdict(float)
+for k, v in rows.items():
+    if family(k):
+        dur[family(k)] += sum(v)
 with open(out + "/pmc_summary.txt", "w") as o:
-    o.write("per launch of cosim::env_kernel, rocprofv3 --pmc passes over: bench.py --workload $WL --steps $STEPS --warmup 10\n")
-    for k in sorted(tot):
-        o.write(f"{k:28s} per-launch {tot[k]/cnt[k]:16.1f}   launches {cnt[k]}\n")
+    for fam in sorted(tot, key=lambda f: -dur[f]):
+        o.write(f"per launch of cosim::{fam}, rocprofv3 --pmc passes over: bench.py --workload $WL --steps $STEPS --warmup 10\n")
+        for k in sorted(tot[fam]):
+            o.write(f"{k:28s} per-launch {tot[fam][k]/cnt[fam][k]:16.1f}   launches {cnt[fam][k]}\n")
 print(open(out + "/kernel_trace_summary.txt").read()[:3000])
 print(open(out + "/pmc_summary.txt").read())
 print(open(out + "/bench_line.json").read()[:600])
