@@ -417,6 +417,7 @@ def main(argv=None):
         value = world * n * args.steps / dt
         balg = b_alg(env.nq, env.nv, nu, env.state_dim)
         achieved = balg * ns / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0   # one launch processes ns envs
+        split_waves = env.engine.query("split")
         pmc = pmc_traffic(args.workload)
         valu = pmc.pop("valu_insts_per_launch", None)
         pmc.pop("pmc_file", None)
@@ -450,7 +451,10 @@ def main(argv=None):
                          # per launch as the contract defines it (S launches overlap on the chip); the whole fleet per control step:
                          "achieved_fleet": balg * n / (dt / args.steps) / 1e9,
                          "frac_fleet": balg * n / (dt / args.steps) / 1e9 / HBM_PEAK_GBS,
-                         "kernel": f"cosim::env_kernel<{env.nv},{env.cm.blob.nbody},...>", "kernel_ms": kernel_ms, "launches": launches,
+                         "kernel": (f"cosim::env_kernel<{env.nv},{env.cm.blob.nbody},...>" if not split_waves else
+                                    f"cosim::env_narrow_kernel + env_step_kernel<{env.nv},{env.cm.blob.nbody},...>: one pair of launches per substep, "
+                                    f"{split_waves} narrowphase waves per env; kernel_ms is the whole control step's launches on one range stream"),
+                         "kernel_ms": kernel_ms, "launches": launches,
                          "algorithmic_bytes_per_env_step": balg,
                          "note": "latency/VALU-bound small-state solver; HBM sees only the compulsory state traffic (SURVEY §8d)"},
         }
