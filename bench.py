@@ -182,10 +182,13 @@ def _cpu_worker_entry(k):
     return _CPU_WORKER(k)
 
 
-def pmc_traffic(workload):
+def pmc_traffic(workload, split_substeps=0):
     """HBM bytes per launch of the step kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate
     passes over this same command: tools/pmc_run.sh -> profiles/rNN_pmc_summary_<workload>.txt).  Counters cannot be read from
-    inside the timed run, so the figure is the one measured for the committed kernel; null for workloads without a PMC pass."""
+    inside the timed run, so the figure is the one measured for the committed kernel; null for workloads without a PMC pass.
+    The summary has one section per kernel, the one with the most GPU time first: that section is "the dominant kernel".
+    split_substeps > 0 (the two-kernel pipeline): what one timed unit covers is a whole control step on one range stream, i.e.
+    split_substeps launches of the narrowphase kernel and of the solver kernel: their sections are added up accordingly."""
     import glob
     import re
     root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
@@ -195,26 +198,40 @@ def pmc_traffic(workload):
     files.sort(key=lambda f: [int(x) for x in re.findall(r"\d+", os.path.basename(f))])
     if not files:
         return {"traffic": None}
-    vals, valu, sections = {}, None, 0
+    sections, cur = [], None
     for line in open(files[-1]):
         if line.startswith("per launch of"):
-            sections += 1
-            if sections > 1:
-                break                                                # first section = the kernel with the most GPU time
+            cur = {"kernel": line.split()[3].rstrip(",")}
+            sections.append(cur)
+            continue
         t = line.split()
-        if len(t) >= 3 and t[0] in ("FETCH_SIZE", "WRITE_SIZE"):
-            vals[t[0]] = float(t[2]) * 1024.0                        # rocprofv3 reports both in KiB
-        if len(t) >= 3 and t[0] == "SQ_INSTS_VALU":
-            valu = float(t[2])
-    if len(vals) != 2:
+        if cur is not None and len(t) >= 3 and t[0] in ("FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_VALU"):
+            cur[t[0]] = float(t[2]) * (1024.0 if t[0] != "SQ_INSTS_VALU" else 1.0)    # rocprofv3 reports the sizes in KiB
+    if not sections:                                                  # round-1 / round-2 files: one unnamed section
+        cur = {"kernel": "cosim::env_kernel"}
+        for line in open(files[-1]):
+            t = line.split()
+            if len(t) >= 3 and t[0] in ("FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_VALU"):
+                cur[t[0]] = float(t[2]) * (1024.0 if t[0] != "SQ_INSTS_VALU" else 1.0)
+        sections = [cur]
+    use = [x for x in sections if "FETCH_SIZE" in x and "WRITE_SIZE" in x]
+    if split_substeps > 0:
+        use = [x for x in use if "narrow" in x["kernel"] or "step_kernel" in x["kernel"]]
+        mult = float(split_substeps)
+    else:
+        use, mult = use[:1], 1.0
+    if not use:
         return {"traffic": None}
-    extra = {"valu_insts_per_launch": valu, "pmc_file": os.path.basename(files[-1])} if valu else {}
+    fetch, write = mult * sum(x["FETCH_SIZE"] for x in use), mult * sum(x["WRITE_SIZE"] for x in use)
+    valu = mult * sum(x.get("SQ_INSTS_VALU", 0.0) for x in use)
+    extra = {"valu_insts_per_launch": valu} if valu else {}
     # gfx950: FETCH_SIZE tallies 128-B requests at 64 B (MI355X_MICROARCH.md, HBM / rocprofv3 section): doubled, as the guide
     # prescribes, before it is compared with a byte count (an upper bound here: the guide calibrates the factor on 16-B-per-lane
     # streaming reads, this kernel reads a dword per lane); WRITE_SIZE is exact
-    return {"traffic": 2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"],
-            "traffic_note": f"bytes per launch, {os.path.basename(files[-1])}: 2 x FETCH_SIZE {vals['FETCH_SIZE']:.3g} B (gfx950 correction of "
-                            f"the guide; face value would be the lower bound) + WRITE_SIZE {vals['WRITE_SIZE']:.3g} B (state, observation stack "
+    return {"traffic": 2.0 * fetch + write,
+            "traffic_note": f"bytes per timed unit ({' + '.join(x['kernel'] for x in use)}{f' x {split_substeps} substeps' if split_substeps else ''}), "
+                            f"{os.path.basename(files[-1])}: 2 x FETCH_SIZE {fetch:.3g} B (gfx950 correction of "
+                            f"the guide; face value would be the lower bound) + WRITE_SIZE {write:.3g} B (state, observation stack "
                             "and info write-back, plus register-spill scratch in the kernels that spill)", **extra}
 
 
@@ -418,9 +435,8 @@ def main(argv=None):
         balg = b_alg(env.nq, env.nv, nu, env.state_dim)
         achieved = balg * ns / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0   # one launch processes ns envs
         split_waves = env.engine.query("split")
-        pmc = pmc_traffic(args.workload)
+        pmc = pmc_traffic(args.workload, int(env.cm.blob.frame_skip) if split_waves else 0)
         valu = pmc.pop("valu_insts_per_launch", None)
-        pmc.pop("pmc_file", None)
         if valu:
             # VALU issue rate against the chip's issue slots: wave-level VALU instructions per launch (PMC pass of the committed kernel)
             # x this run's launches / this run's timed seconds, over 1024 SIMDs x 2.4 GHz / 2 (a wave64 fp32 VALU instruction holds its
