@@ -561,16 +561,20 @@ def test_other_robots_one_control_step_replay_flat(env_id, steps):
     np.testing.assert_allclose(info["torque"].cpu().numpy(), R["tq"], rtol=1e-4, atol=2e-3)
     st = env.solver_stats()
     assert st["dropped_contacts"] == 0 and st["dropped_limit_rows"] == 0    # every state runs with its full constraint set
-    ok = np.ones(steps, bool)
-    ep = np.abs(qp[ok] - R["qpos1"][ok]).max(axis=1)
+    ep = np.abs(qp - R["qpos1"]).max(axis=1)
     # a contact that switches on within round-off of the threshold moves a state by a few 1e-4: judged by quantile, bounded by max
     assert np.quantile(ep, 0.97) < 2e-4 and ep.max() < 2e-3, (np.quantile(ep, 0.97), ep.max())
-    ev = np.abs(qv[ok] - R["qvel1"][ok]).max(axis=1)
+    ev = np.abs(qv - R["qvel1"]).max(axis=1)
     assert np.quantile(ev, 0.97) < 2e-2 and np.median(ev) < 2e-3 and ev.max() < 0.5, (ev.max(), np.quantile(ev, 0.97), np.median(ev))
+    # the tail as a number per run (states whose step crossed a contact-onset threshold differently in fp32 and fp64)
+    print(f"[replay {env_id}] states {len(ev)}: |dqvel| > 5e-3 rad/s in {(ev > 5e-3).mean():.3%}, > 5e-2 in {(ev > 5e-2).mean():.3%}; "
+          f"|dqpos| > 1e-4 in {(ep > 1e-4).mean():.3%}")
     if b.term_mode == 1:
         got = term.cpu().numpy().astype(bool)
         # cfrc_ext termination (flamingo_p_v3.py:225-233): agree except within round-off of the 1.0 threshold
-        assert (got[ok] == R["term"][ok]).mean() > 0.9
+        agree = (got == R["term"]).mean()
+        print(f"[replay {env_id}] termination flags agree on {agree:.3%} of {len(got)} states ({int(R['term'].sum())} terminal in the oracle)")
+        assert agree > 0.9
     env.close()
 
 
