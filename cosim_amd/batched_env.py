@@ -89,7 +89,9 @@ class BatchedEnv:
         call ``join()`` before consuming ``state`` / ``terminated`` / ``info`` on the current stream (``get_data``, ``reset``,
         ``event``, ``set_state`` and ``solver_stats`` join by themselves).  That is what lets a range's next control step overlap
         the tail of the others' current one; it fits callers whose next action does not need the whole fleet's last state (an
-        action table; a policy evaluated per range on ``range_streams``).  Defaults: ``config["engine"]`` / 1 / False."""
+        action table; a policy evaluated per range on ``range_streams``).  With a deferred join the ``action`` tensor of a step must
+        stay untouched until that step has run (at most two steps are in flight: an action table or three rotating buffers), and
+        ``receive_user_command`` joins first.  Defaults: ``config["engine"]`` / 1 / False."""
         import torch  # plumbing only
 
         eng_cfg = config.get("engine", {})
@@ -215,11 +217,22 @@ class BatchedEnv:
         """Store the raw user command(s); scaling / position-mode transform happen in the next kernel launch
         from the pre-step pose, exactly where ``CommandWrapper.receive_user_command`` reads ``get_data()``."""
         t = self.torch
+        if not t.is_tensor(user_command):
+            # the same command as last time (the reference's loop re-sends it every step, core/tester.py:68): nothing to write
+            host = np.ascontiguousarray(user_command, dtype=np.float32)
+            last = getattr(self, "_last_cmd_host", None)
+            if last is not None and last.shape == host.shape and np.array_equal(last, host):
+                return
+            self._last_cmd_host = host.copy()
+        else:
+            self._last_cmd_host = None
         uc = t.as_tensor(user_command, dtype=t.float32, device=self.device)
         if uc.ndim == 1:
             uc = uc[None, :].expand(self.num_envs, -1)
         if self.config["env"]["position_command"] is not False:
             assert self.command_dim == 2, f"Currently, position command only support 2 dimenstion, but got {self.command_dim}."
+        if self.ranges > 1 and self.deferred_join:
+            self.engine.join(self._stream())          # steps in flight still read the command buffer: write it behind them
         self.user_command[:, :self.command_dim] = uc[:, :self.command_dim]
 
     def reset(self, mask=None):

@@ -116,7 +116,10 @@ int cosim_step(cosim_engine_t* e, const float* actions_dev, const float* command
  * cosim_reset / cosim_get / cosim_set / cosim_event_push (they join first).  A deferred join is what lets a range's next control
  * step start while the other ranges are still inside the current one (a launch ends with its slowest env): a caller whose next
  * actions do not depend on the whole fleet's last outputs (an action table, or a policy evaluated per range on the range's stream:
- * cosim_range) calls cosim_step back to back and joins when it reads results.  (The reference steps one env: core/tester.py:90.) */
+ * cosim_range) calls cosim_step back to back and joins when it reads results.  With a deferred join the INPUT buffers of a step (actions_dev,
+ * commands_dev) must stay untouched until that step has run: at most "inflight" (default 2) steps are in flight, so rotating three
+ * action buffers, or an action table, is enough; the output buffers hold the newest step's results after the join.
+ * (The reference steps one env: core/tester.py:90.) */
 int cosim_join(cosim_engine_t* e, void* stream);
 /* Range i of "ranges": its first env, env count and stream (hipStream_t; NULL when ranges == 1).  Work enqueued on that stream from
  * outside (a per-range policy, a reporter reduction) is ordered with the range's steps; cosim_range_mark(i) re-arms the range's
