@@ -421,3 +421,46 @@ def test_lstm_cell_kernel_matches_the_fp64_cell(tmp_path, I, H, n):
     pol.reset(mask)
     hh = pol.h_in[0].cpu().numpy()
     assert np.abs(hh[::3]).max() == 0.0 and np.abs(hh[1::3]).max() > 0.0
+
+
+def test_range_launches_inside_a_captured_graph_equal_the_eager_loop():
+    """cosim_step with engine-owned ranges is capturable: the fork (range streams wait for the capturing stream) and the join
+    (``env.join()`` before the capture ends) tie the range streams into the graph; inside it the range chains of consecutive steps
+    stay independent (deferred join).  Three control steps per replay, several replays: the bits of the eager loop."""
+    import torch
+    from cosim_amd.batched_env import BatchedEnv
+    from cosim_amd.config import make_config
+    cfg = make_config("flamingo_light_v1", num_envs=256, seed=9)
+    n, K, R = 256, 3, 4
+    acts = (0.3 * torch.randn((K, n, 4), device="cuda:0", generator=torch.Generator(device="cuda:0").manual_seed(2))).contiguous()
+    outs = []
+    for graphed in (False, True):
+        env = BatchedEnv(cfg, num_envs=n, seed=9, auto_reset=True, ranges=4, deferred_join=True)
+        env.receive_user_command(np.array([0.5, 0.0, 0.0, 0.0], dtype=np.float32))
+        env.reset()
+        torch.cuda.synchronize()
+
+        def chunk():
+            for k in range(K):
+                env.step(acts[k])
+            env.join()
+        if graphed:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                chunk()                              # warm-up outside the capture (one chunk of the R)
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                chunk()
+            for _ in range(R - 1):
+                g.replay()
+        else:
+            for _ in range(R):
+                chunk()
+        torch.cuda.synchronize()
+        outs.append((env.state.clone(), env.get_data().qpos.clone(), env.solver_stats()["step_count"]))
+        env.close()
+    assert outs[0][2] == outs[1][2] == n * (1 + K * R)
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
