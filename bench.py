@@ -297,6 +297,7 @@ def main(argv=None):
                          "of the others' launches); 1 = one launch on the caller's stream")
     ap.add_argument("--caller-streams", action="store_true",
                     help="A/B: the round-2 arrangement, the CALLER builds the S streams and calls env.step_range per range")
+    ap.add_argument("--no-rollout", action="store_true", help="skip the extra cosim_rollout measurement after the timed region")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse ranks on one GPU)")
     ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses cuda:0 (with --backend gloo)")
     ap.add_argument("--report-every", type=int, default=16, help="reporter statistics are sampled every this many timed steps")
@@ -430,6 +431,25 @@ def main(argv=None):
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
 
+    # A second, separately labelled number (never `value`): the same fleet continuing for another args.steps control steps through
+    # cosim_rollout -- the whole table in one launch per range, for callers whose actions do not depend on the last state.
+    rollout = None
+    if env.engine.query("rollout") == 1 and not args.caller_streams and not args.no_rollout:
+        acts_r = synthetic_actions(n, env_id0, total_steps + args.steps, nu, env.device)[total_steps:].contiguous()
+        env.rollout(acts_r[:min(2, args.steps)])            # code-object load of the rollout kernels
+        sync()
+        tr0 = time.perf_counter()
+        env.rollout(acts_r)
+        sync()
+        tr = torch.tensor([time.perf_counter() - tr0], dtype=torch.float64, device=env.device)
+        if world > 1:
+            dist.all_reduce(tr, op=dist.ReduceOp.MAX)
+        str_ = env.solver_stats()
+        rollout = {"env_steps_per_s": world * n * args.steps / float(tr.item()), "steps_per_launch": args.steps,
+                   "api": "env.rollout(action_table) -> cosim_rollout", "dropped_contacts": str_["dropped_contacts"],
+                   "finite": bool(torch.isfinite(env.state).all().item()),
+                   "note": "same fleet, the next `steps` rows of the same action table, outputs for every step written; not the headline"}
+
     if rank == 0:
         value = world * n * args.steps / dt
         balg = b_alg(env.nq, env.nv, nu, env.state_dim)
@@ -461,7 +481,8 @@ def main(argv=None):
                        # control steps redone by the large-capacity kernel (contacts beyond the fleet kernel's slots); 0 slots: the
                        # workload's kernel has no such sibling and counts what it leaves out in dropped_contacts
                        "fixup_steps": st["fixup_steps"], "fixup_contact_slots": env.engine.query("fixup_contact_slots"),
-                       "step_api": "caller streams + env.step_range" if args.caller_streams else "env.step"},
+                       "step_api": "caller streams + env.step_range" if args.caller_streams else "env.step",
+                       "rollout": rollout},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, **pmc,
                          # per launch as the contract defines it (S launches overlap on the chip); the whole fleet per control step:

@@ -258,6 +258,28 @@ class BatchedEnv:
             raise ValueError(f"Invalid 'command_dim': expected 0> or <7; but got {self.command_dim}.")
         return self.state, self.terminated, self.truncated, self._info(a)
 
+    def rollout(self, actions, info: bool = True):
+        """``len(actions)`` control steps of the whole fleet under an action table ``[K, N, action_dim]`` in one launch per range
+        (``cosim_rollout``: the reference's ``Tester.test`` loop, core/tester.py:66-97, with the policy replaced by a lookup).
+        Returns ``(states [K, N, state_dim], terminated [K, N], truncated [K, N], info_buf [K, N, info_dim] or None)``: row k is what
+        ``step(actions[k])`` would have returned (auto-reset included).  ``self.state`` etc. keep the last row."""
+        assert self.reset_flag is True, "Call 'reset()' before calling 'step()'."
+        t = self.torch
+        a = t.as_tensor(actions, dtype=t.float32, device=self.device).contiguous()
+        if a.ndim != 3 or tuple(a.shape[1:]) != (self.num_envs, self.action_dim):
+            raise ValueError(f"Action table mismatch. Expected [K, {self.num_envs}, {self.action_dim}], found {tuple(a.shape)}")
+        K = a.shape[0]
+        states = t.empty((K, self.num_envs, self.state_dim), dtype=t.float32, device=self.device)
+        term = t.empty((K, self.num_envs), dtype=t.uint8, device=self.device)
+        trunc = t.empty((K, self.num_envs), dtype=t.uint8, device=self.device)
+        inf = t.empty((K, self.num_envs, self.info_dim), dtype=t.float32, device=self.device) if info else None
+        self.engine.rollout(K, a.data_ptr(), self._cmd_ptr(), states.data_ptr(), term.data_ptr(), trunc.data_ptr(),
+                            inf.data_ptr() if info else None, self._stream())
+        self.state.copy_(states[-1]); self.terminated.copy_(term[-1]); self.truncated.copy_(trunc[-1])
+        if info:
+            self.info_buf.copy_(inf[-1])
+        return states, term, trunc, inf
+
     def step_range(self, first: int, count: int, action):
         """One control step of envs ``[first, first + count)`` on the current stream (``cosim_step_range``): ``action`` is the
         whole fleet's ``[N, action_dim]`` tensor; outputs land in the fleet's ``state`` / ``terminated`` / ``truncated`` /

@@ -81,6 +81,9 @@ struct cosim_engine {
   float *d_xcon = nullptr, *d_xstate = nullptr;
   int* d_xcnt = nullptr;
   int* d_ovf = nullptr;   // [n_envs] flags, set by the fleet kernel, cleared by the fix-up kernel
+  // rollout launches (cosim_rollout): K control steps per launch where the variant has such a kernel
+  void (*launch_roll)(cosim_engine*, const KArgs&, int grid, hipStream_t) = nullptr;
+  void (*launch_roll_fix)(cosim_engine*, const KArgs&, int grid, hipStream_t) = nullptr;
   // range launches: cosim_step issues the fleet as n_ranges launches over contiguous env ranges on engine-owned streams, so that a
   // range's next control step fills the tail of the others' launches (a launch ends with its slowest env)
   int n_ranges = 1;
@@ -121,6 +124,14 @@ static void launch_narrow_t(cosim_engine* e, const KArgs& a, int grid, hipStream
 template <int NV, int NB, int RPL, bool HF, int GTM, bool SC, int MCT>
 static void launch_stepx_t(cosim_engine* e, const KArgs& a, int grid, hipStream_t s) {
   hipLaunchKernelGGL((env_step_kernel<NV, NB, RPL, HF, GTM, SC, MCT>), dim3(grid), dim3(64), 0, s, a);
+}
+template <int NV, int NB, int RPL, bool HF, int GTM, bool SC, int MCT>
+static void launch_roll_t(cosim_engine* e, const KArgs& a, int grid, hipStream_t s) {
+  hipLaunchKernelGGL((env_rollout_kernel<NV, NB, RPL, HF, GTM, SC, MCT>), dim3(grid), dim3(64), 0, s, a);
+}
+template <int NV, int NB, int RPL, bool HF, int GTM, bool SC, int MCT>
+static void launch_roll_fix_t(cosim_engine* e, const KArgs& a, int grid, hipStream_t s) {   // grid = envs of the range
+  hipLaunchKernelGGL((env_rollout_fix_kernel<NV, NB, RPL, HF, GTM, SC, MCT>), dim3((grid + 63) / 64), dim3(64), 0, s, a);
 }
 template <int NV, int NB, int GTM>
 static void launch2_t(cosim_engine* e, const KArgs& a, int grid, hipStream_t s) {   // grid = number of envs
@@ -561,6 +572,8 @@ int cosim_create(const cosim_model_t* model, const float* hull_vert, const int* 
       // can emit) as the kernel that redoes the rare control step with more than 14 contacts: nothing is ever left out
       e->launch_fix = launch_fix_t<18, 14, 1, false, G_LIGHT, false, 40>;
       e->fix_contact_slots = 40;
+      e->launch_roll = launch_roll_t<18, 14, 1, false, G_LIGHT, false, 0>;
+      e->launch_roll_fix = launch_roll_fix_t<18, 14, 1, false, G_LIGHT, false, 40>;
     }
   }
   else if (nv == 14 && nb <= 10 && (gtm & ~G_MESH) == 0) {   // flamingo_p_v3
@@ -582,6 +595,8 @@ int cosim_create(const cosim_model_t* model, const float* hull_vert, const int* 
       e->lds_bytes = (int)sizeof(LD_); e->contact_slots = LD_::MC; e->pair_slots = 0;
       e->launch_fix = launch_fix_t<14, 10, 1, false, G_MESH, true, 32>;
       e->fix_contact_slots = 32;
+      e->launch_roll = launch_roll_t<14, 10, 1, false, G_MESH, true, 0>;
+      e->launch_roll_fix = launch_roll_fix_t<14, 10, 1, false, G_MESH, true, 32>;
     }
   }
   else if (nv == 22 && nb <= 18 && (gtm & ~G_MESH) == 0) {   // w4_p_v2
@@ -689,6 +704,7 @@ int cosim_query(const cosim_engine_t* e, const char* name) {
   if (n == "contact_slots") return e->contact_slots;
   if (n == "fixup_contact_slots") return e->launch_fix ? e->fix_contact_slots : 0;   // 0: no large-capacity kernel behind this one
   if (n == "ranges") return e->n_ranges;
+  if (n == "rollout") return e->launch_roll && e->epw == 1 ? 1 : 0;   // 1: cosim_rollout is available for this model / terrain
   if (n == "split") return (e->split && e->launch_stepx) ? e->narrow_waves : 0;   // waves per env of the narrowphase kernel; 0: fused kernel
   if (n == "pair_slots") return e->pair_slots;
   if (n == "stacked_dim") return e->ho.stacked_dim;
@@ -744,14 +760,14 @@ int cosim_set_param(cosim_engine_t* e, const char* name, const float* host, int 
   }
   else if (n == "narrow_occupancy") { e->narrow_occ = (int)host[0]; return COSIM_OK; }   // 2 | 3 | 4 (tuning)
   else if (n == "fixup") {   // 0: no fix-up launches (contacts beyond the fleet kernel's slots are left out and counted, as in round 2)
-    if ((int)host[0] == 0) e->launch_fix = nullptr;
+    if ((int)host[0] == 0) { e->launch_fix = nullptr; if (e->launch_roll_fix) { e->launch_roll = nullptr; e->launch_roll_fix = nullptr; } }
     return COSIM_OK;
   }
   else if (n == "contact_twist") {   // 1: switch a dense-row kernel to its contact-twist variant (more contact slots), where one exists
     if ((int)host[0] != 0) {
       if (!e->launch_ct) return fail(COSIM_EINVAL, "cosim_set_param: no contact-twist variant for this model / terrain");
       e->launch = e->launch_ct; e->launch_prof = e->launch_ct_prof; e->launch2 = nullptr; e->launch_prof2 = nullptr; e->epw = 1;
-      e->launch_fix = nullptr;
+      e->launch_fix = nullptr; e->launch_roll = nullptr; e->launch_roll_fix = nullptr;
       if (e->model.nv == 14) e->pair_slots = 8;
       e->lds_bytes = e->ct_lds_bytes; e->contact_slots = e->ct_contact_slots;
     }
@@ -794,7 +810,7 @@ static KArgs base_args(cosim_engine* e) {
   a.n_envs = e->n_envs; a.seed_lo = (unsigned)e->seed; a.seed_hi = (unsigned)(e->seed >> 32); a.env_id0 = e->env_id0;
   a.tol32 = e->tol32; a.ls_scale = e->ls_scale; a.max_newton = e->max_newton; a.max_ls = e->max_ls; a.nsub_override = e->nsub_override; a.pair_coop = e->pair_coop; a.pair_boxbox = e->pair_boxbox;
   for (int k = 0; k < 4; k++) a.prio[k] = e->prio[k];
-  a.ovf = nullptr;
+  a.ovf = nullptr; a.roll_steps = 1;
   a.xcon = e->d_xcon; a.xcnt = e->d_xcnt; a.xstate = e->d_xstate; a.nw = e->narrow_waves; a.sub_index = 0; a.sub_total = 0;
   return a;
 }
@@ -860,6 +876,42 @@ int cosim_step(cosim_engine_t* e, const float* actions_dev, const float* command
   if (e->inflight > 0 && cap == hipStreamCaptureStatusNone) e->ring_pos++;
   e->join_pending = true;
   if (!e->deferred_join) return join_ranges(e, cs);
+  return COSIM_OK;
+}
+
+// The reference's loop with an action table (core/tester.py:66-97 with policy.get_action replaced by a lookup): `steps` control steps
+// in ONE launch per range; row k of the [steps][N][...] buffers is what cosim_step would have been given / would have returned at
+// step k.  Returns with the caller's stream waiting for everything (eager join).
+int cosim_rollout(cosim_engine_t* e, int steps, const float* actions_dev, const float* commands_dev, float* state_out_dev, uint8_t* terminated_dev,
+                  uint8_t* truncated_dev, float* info_out_dev, void* stream) {
+  if (!e || !actions_dev || !state_out_dev || !terminated_dev || !truncated_dev || steps < 1) return fail(COSIM_EINVAL, "cosim_rollout: bad argument");
+  if (!e->launch_roll || e->epw != 1) return fail(COSIM_EINVAL, "cosim_rollout: no rollout kernel for this model / terrain / kernel variant");
+  if (e->ho.command_dim > 0 && !commands_dev) return fail(COSIM_EINVAL, "cosim_rollout: commands_dev is required when command_dim > 0");
+  HIP_TRY(hipSetDevice(e->device));
+  int rc = upload_params(e);
+  if (rc) return rc;
+  hipStream_t cs = (hipStream_t)stream;
+  rc = join_ranges(e, cs);
+  if (rc) return rc;
+  KArgs a = base_args(e);
+  a.mode = MODE_STEP; a.actions = actions_dev; a.commands = commands_dev; a.state_out = state_out_dev;
+  a.terminated = terminated_dev; a.truncated = truncated_dev; a.info = info_out_dev; a.roll_steps = steps;
+  a.ovf = e->launch_roll_fix ? e->d_ovf : nullptr;
+  const int nr = e->n_ranges > 1 ? e->n_ranges : 1;
+  if (nr > 1) HIP_TRY(hipEventRecord(e->ev_in, cs));
+  for (int i = 0; i < nr; i++) {
+    hipStream_t s = nr > 1 ? e->rstream[i] : cs;
+    if (nr > 1) HIP_TRY(hipStreamWaitEvent(s, e->ev_in, 0));
+    a.env_first = nr > 1 ? e->rfirst[i] : 0;
+    a.env_count = nr > 1 ? e->rcount[i] : e->n_envs;
+    int slot = -1;
+    if (e->timing && e->ev_used + 2 <= (int)e->ev.size()) { slot = e->ev_used; e->ev_used += 2; HIP_TRY(hipEventRecord(e->ev[slot], s)); }
+    e->launch_roll(e, a, a.env_count, s);
+    HIP_TRY(hipGetLastError());
+    if (slot >= 0) HIP_TRY(hipEventRecord(e->ev[slot + 1], s));
+    if (a.ovf) { e->launch_roll_fix(e, a, a.env_count, s); HIP_TRY(hipGetLastError()); }
+  }
+  if (nr > 1) { e->join_pending = true; return join_ranges(e, cs); }
   return COSIM_OK;
 }
 

@@ -72,6 +72,7 @@ struct KArgs {
   float* xstate;          // [N][XS] what a control step holds across its substep launches: actuation force, raw action, torque
   int sub_index, sub_total;   // this launch is substep sub_index of sub_total (0: the fused kernel, every substep in one launch)
   int nw;                 // narrowphase: waves per env (wave w takes the geoms g with g % nw == w)
+  int roll_steps;         // rollout launch (env_rollout_kernel): control steps per launch; actions / state_out / terminated / truncated / info are then [roll_steps][N][...]
   int* ovf;               // [N] per-env flag "this control step needs the large-capacity kernel" (null: no such kernel; contacts that find no slot are left out and counted)
   int env_count;          // envs of this launch (the fix-up kernel scans ovf[env_first .. env_first + env_count))
 };
@@ -596,7 +597,8 @@ typedef const KArgs __attribute__((address_space(4)))* KArgsP;
 // (A.ovf != null), a step whose contacts do not fit this kernel's slots is abandoned before anything is written and flagged.
 // KM: see KTraits.  wsel: (KM == 1) which of the env's A.nw narrowphase waves this is.
 template <int NV, int NB, int RPL, bool HF, int GTM, bool SC, bool PROF, int EPW, int MCT, bool FIX, int KM = 0>
-__device__ __forceinline__ void env_body(KArgsP kargs_p, const int env, typename KTraits<NV, NB, RPL, HF, SC, EPW, MCT, KM>::L (&SS)[EPW], const int wsel = 0) {
+__device__ __forceinline__ void env_body(KArgsP kargs_p, const int env, typename KTraits<NV, NB, RPL, HF, SC, EPW, MCT, KM>::L (&SS)[EPW], const int wsel = 0,
+                                         const int kstep = 0) {   // kstep: control step of a rollout launch (row of the [K][N][...] I/O buffers)
   static_assert(EPW == 1 || (EPW == 2 && !HF && !SC && NV <= 32 && NB <= 32), "two environments per wave: flat ground, no pairs");
   static_assert(MCT == 0 || EPW == 1, "contact-twist mode: one environment per wave");
   static_assert(KM == 0 || (HF && MCT > 0 && EPW == 1 && !FIX && (!PROF || KM == 1)), "split pipeline: heightfield contact-twist kernels");
@@ -704,7 +706,7 @@ __device__ __forceinline__ void env_body(KArgsP kargs_p, const int env, typename
       const bool delayed = (ob.action_delay_prob > u01(philox_first(k0, k1, step_count, 0u, g0, g1))) && has_prev;  // control_manager.py:15-23
       if (lane < nu) {
         const auto& R = dm.rec[lane];
-        const float raw_action = A.actions[(size_t)env * nu + lane];
+        const float raw_action = A.actions[((size_t)kstep * A.n_envs + env) * nu + lane];
         S.act[lane] = raw_action;
         float filt = delayed ? rec[lay.s_delay + lane] : raw_action;   // (the delay line is rewritten with the state, at the end)
         float a = filt * R.a_scale, g = R.a_cgear;
@@ -1802,7 +1804,7 @@ __device__ __forceinline__ void env_body(KArgsP kargs_p, const int env, typename
           // it has been written) and flag the env; env_fixup_kernel redoes it from the same state right after this launch
           // (readfirstlane: heightfield kernels read the count from LDS, which the compiler must take for a per-lane value)
           if (kmode == MODE_STEP && A.ovf != nullptr && __builtin_amdgcn_readfirstlane(ncon_all - ncon - npc) > 0) {
-            if (ln == 0) A.ovf[env] = 1;
+            if (ln == 0) A.ovf[env] = 1 + kstep;   // (rollout launch: the step the large-capacity kernel takes over at)
             return;
           }
         }
@@ -2638,7 +2640,7 @@ __device__ __forceinline__ void env_body(KArgsP kargs_p, const int env, typename
   if (kmode == MODE_STEP) {
     WSYNC();
     if (A.info != nullptr) {
-      float* inf = A.info + (size_t)env * ob.info_dim;
+      float* inf = A.info + ((size_t)kstep * A.n_envs + env) * ob.info_dim;
       const float raw_action = lane < nu ? S.act[lane] : 0.f;
       const float prev_action = lane < nu ? rec[lay.s_lastact + lane] : 0.f;   // still the previous step's action (zeros after a reset)
       float dsq = lane < nu ? (raw_action - prev_action) * (raw_action - prev_action) : 0.f;
@@ -2650,7 +2652,7 @@ __device__ __forceinline__ void env_body(KArgsP kargs_p, const int env, typename
         inf[4 + 2 * nu + lane] = (R.i_kind == 0 ? S.qpos[R.i_adr] : S.qvel[R.i_adr]) * R.i_gear;
       }
     }
-    if (lane == 0) { A.terminated[env] = (uint8_t)terminated; A.truncated[env] = (uint8_t)truncated; }
+    if (lane == 0) { A.terminated[(size_t)kstep * A.n_envs + env] = (uint8_t)terminated; A.truncated[(size_t)kstep * A.n_envs + env] = (uint8_t)truncated; }
   }
 
   // =============================================================== reset_model (flamingo_light_v1.py:209-232)
@@ -2685,7 +2687,7 @@ __device__ __forceinline__ void env_body(KArgsP kargs_p, const int env, typename
     q2m(m, s_quat);
     const float pg[3] = {-m[6], -m[7], -m[8]};  // R^T (0,0,-1)
     const bool fill = do_reset;                 // reset fills every stack row with the first frame
-    float* so = A.state_out + (size_t)env * ob.state_dim;
+    float* so = A.state_out + ((size_t)kstep * A.n_envs + env) * ob.state_dim;
     const int sd = ob.stacked_dim, S_ = ob.stack_size;
     for (int e = lane; e < ob.frame_dim; e += LW) {
       const int f = ob.el_field[e], idx = ob.el_index[e];
@@ -2836,6 +2838,52 @@ __global__ __launch_bounds__(64, waves_per_simd(163840 / (int)sizeof(typename KT
   const int env = A.mode == MODE_DEBUG ? A.dbg_env : A.env_first + (int)blockIdx.x;
   if (env >= A.n_envs) return;
   env_body<NV, NB, RPL, HF, GTM, SC, false, 1, MCT, false, 2>(kargs_p, env, SS);
+}
+
+// Rollout launch: the reference's loop (core/tester.py:66-97) with the policy replaced by an action table, K control steps per
+// launch.  A wave stays on its env for all K steps, so no env waits for the slowest env of its launch at every step (the tail that
+// range launches only partly fill); every step's state vector, flags and info go to row k of [K][N][...] buffers.  Between two steps
+// the wave's own stores must be what its loads see: release / acquire at agent scope (write-back + L1 invalidate).  A dense fleet
+// kernel that meets more contacts than it has slots at step k flags the env with k + 1 and leaves: env_rollout_fix_kernel takes the
+// env from step k to the end with the large-capacity body.
+template <int NV, int NB, int RPL, bool HF, int GTM, bool SC, int MCT>
+__global__ __launch_bounds__(64, waves_per_simd(163840 / (int)sizeof(typename KTraits<NV, NB, RPL, HF, SC, 1, MCT>::L))) void env_rollout_kernel(KArgs kernarg_block) {
+  KArgsP kargs_p = (KArgsP)__builtin_amdgcn_kernarg_segment_ptr();
+  (void)kernarg_block;
+  __shared__ typename KTraits<NV, NB, RPL, HF, SC, 1, MCT>::L SS[1];
+  const int env = A.env_first + (int)blockIdx.x;
+  if (env >= A.n_envs) return;
+  const int K = A.roll_steps;
+#pragma nounroll
+  for (int k = 0; k < K; k++) {
+    env_body<NV, NB, RPL, HF, GTM, SC, false, 1, MCT, false>(kargs_p, env, SS, 0, k);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    if (A.ovf != nullptr && __builtin_amdgcn_readfirstlane(A.ovf[env]) != 0) break;   // abandoned at step k: the fix kernel continues
+  }
+}
+template <int NV, int NB, int RPL, bool HF, int GTM, bool SC, int MCT>
+__global__ __launch_bounds__(64, 4) void env_rollout_fix_kernel(KArgs kernarg_block) {
+  KArgsP kargs_p = (KArgsP)__builtin_amdgcn_kernarg_segment_ptr();
+  (void)kernarg_block;
+  __shared__ typename KTraits<NV, NB, RPL, HF, SC, 1, MCT>::L SS[1];
+  const int base = A.env_first + (int)blockIdx.x * 64, e = base + (int)threadIdx.x;
+  const int fl = (e < A.env_first + A.env_count && e < A.n_envs) ? A.ovf[e] : 0;
+  unsigned long long m = __ballot(fl != 0);
+  const int K = A.roll_steps;
+#pragma nounroll
+  while (m) {   // wave-uniform
+    const int src = __builtin_ctzll(m), env = base + src;
+    m &= m - 1;
+    const int k0 = __builtin_amdgcn_readlane(fl, src) - 1;
+#pragma nounroll
+    for (int k = k0; k < K; k++) {
+      env_body<NV, NB, RPL, HF, GTM, SC, false, 1, MCT, true>(kargs_p, env, SS, 0, k);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    WSYNC();
+  }
 }
 
 // The large-capacity kernel behind a fleet kernel whose contact slots can run out (flamingo_light_v1 on the plane: 14 dense

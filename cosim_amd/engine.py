@@ -92,6 +92,7 @@ def load_library():
     L.cosim_step.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp]
     L.cosim_step_range.argtypes = [vp, ci, ci, vp, vp, vp, vp, vp, vp, vp]
     L.cosim_join.argtypes = [vp, vp]
+    L.cosim_rollout.argtypes = [vp, ci, vp, vp, vp, vp, vp, vp, vp]
     L.cosim_range.argtypes = [vp, ci, ctypes.POINTER(ci), ctypes.POINTER(ci), ctypes.POINTER(vp)]
     L.cosim_range_mark.argtypes = [vp, ci]
     L.cosim_get.argtypes = [vp, ctypes.c_char_p, vp, vp]
@@ -103,7 +104,7 @@ def load_library():
     L.cosim_profile_step.argtypes = [vp] * 7
     L.cosim_last_error.restype = ctypes.c_char_p
     for fn in ("cosim_create", "cosim_destroy", "cosim_query", "cosim_set_param", "cosim_reset", "cosim_step", "cosim_step_range", "cosim_get",
-               "cosim_join", "cosim_range", "cosim_range_mark", "cosim_debug_counters",
+               "cosim_join", "cosim_range", "cosim_range_mark", "cosim_debug_counters", "cosim_rollout", "cosim_rollout",
                "cosim_set", "cosim_event_push", "cosim_debug_forward", "cosim_kernel_time", "cosim_set_timing",
                "cosim_profile_step", "cosim_model_sizeof", "cosim_obs_config_sizeof"):
         getattr(L, fn).restype = ci
@@ -116,7 +117,7 @@ def load_library():
 
 
 EXPORTS = ["cosim_create", "cosim_destroy", "cosim_query", "cosim_set_param", "cosim_reset", "cosim_step", "cosim_step_range", "cosim_get",
-           "cosim_join", "cosim_range", "cosim_range_mark", "cosim_debug_counters",
+           "cosim_join", "cosim_range", "cosim_range_mark", "cosim_debug_counters", "cosim_rollout",
            "cosim_set", "cosim_event_push", "cosim_debug_forward", "cosim_kernel_time", "cosim_set_timing",
            "cosim_profile_step", "cosim_mlp_forward", "cosim_lstm_cell", "cosim_fleet_stats", "cosim_fleet_hist", "cosim_last_error", "cosim_model_sizeof", "cosim_obs_config_sizeof"]
 
@@ -239,6 +240,9 @@ class Engine:
     def step_range(self, first, count, actions_ptr, commands_ptr, state_out_ptr, term_ptr, trunc_ptr, info_ptr, stream=None):
         self._check(self.L.cosim_step_range(self.h, int(first), int(count), actions_ptr, commands_ptr, state_out_ptr, term_ptr, trunc_ptr,
                                             info_ptr, stream))
+
+    def rollout(self, steps, actions_ptr, commands_ptr, state_out_ptr, term_ptr, trunc_ptr, info_ptr, stream=None):
+        self._check(self.L.cosim_rollout(self.h, int(steps), actions_ptr, commands_ptr, state_out_ptr, term_ptr, trunc_ptr, info_ptr, stream))
 
     def join(self, stream=None):
         self._check(self.L.cosim_join(self.h, stream))

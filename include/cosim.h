@@ -120,6 +120,15 @@ int cosim_step(cosim_engine_t* e, const float* actions_dev, const float* command
  * commands_dev) must stay untouched until that step has run: at most "inflight" (default 2) steps are in flight, so rotating three
  * action buffers, or an action table, is enough; the output buffers hold the newest step's results after the join.
  * (The reference steps one env: core/tester.py:90.) */
+/* The reference's loop itself (core/tester.py:66-97: command -> policy -> step -> reporter, until done) with the policy replaced by an
+ * action table: `steps` control steps in ONE launch per range.  actions_dev is [steps][N][nu]; state_out_dev [steps][N][state_dim],
+ * terminated_dev / truncated_dev [steps][N], info_out_dev [steps][N][info_dim] or NULL: row k holds what cosim_step would have been
+ * given / would have returned at step k (auto-reset included); commands_dev [N][command_dim] holds for the whole rollout.  A wave
+ * stays on its env for all the steps, so no env waits at every step for the slowest env of its launch.  Envs that a dense fleet
+ * kernel abandons at step k (more contacts than slots) finish the rollout in the large-capacity kernel.  Available where
+ * cosim_query "rollout" is 1; the caller's stream waits for the whole rollout on return. */
+int cosim_rollout(cosim_engine_t* e, int steps, const float* actions_dev, const float* commands_dev, float* state_out_dev, uint8_t* terminated_dev,
+                  uint8_t* truncated_dev, float* info_out_dev, void* stream);
 int cosim_join(cosim_engine_t* e, void* stream);
 /* Range i of "ranges": its first env, env count and stream (hipStream_t; NULL when ranges == 1).  Work enqueued on that stream from
  * outside (a per-range policy, a reporter reduction) is ordered with the range's steps; cosim_range_mark(i) re-arms the range's

@@ -464,3 +464,65 @@ def test_range_launches_inside_a_captured_graph_equal_the_eager_loop():
         env.close()
     assert outs[0][2] == outs[1][2] == n * (1 + K * R)
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+
+
+@pytest.mark.parametrize("env_id,terrain,ranges", [("flamingo_light_v1", "flat", 1), ("flamingo_light_v1", "flat", 4),
+                                                    ("flamingo_p_v3", "flat", 2)])
+def test_rollout_rows_equal_the_step_loop(env_id, terrain, ranges):
+    """cosim_rollout (K control steps in one launch per range) against K cosim_step calls on a twin fleet: row k of the rollout
+    is what step k returned -- bit for bit for every env whose steps all stayed in the fleet kernel.  An env the dense fleet kernel
+    abandons at step k finishes the rollout in the large-capacity kernel (contact-twist rows instead of dense rows from k+1 on,
+    other rounding): those envs are held to a tolerance until the first episode end after k, and must be few."""
+    import torch
+    from cosim_amd.batched_env import BatchedEnv
+    from cosim_amd.config import make_config
+    n, K = 192, 120
+    cfg = make_config(env_id, terrain=terrain, num_envs=n, seed=21, max_duration=1.6)      # 80-step episodes: auto-reset inside the table
+    cmd = np.array([0.6, 0.0, 0.2, 0.0], dtype=np.float32)
+    a = BatchedEnv(cfg, num_envs=n, seed=21, auto_reset=True, gain_noise=0.1)
+    acts = (0.4 * torch.randn((K, n, a.action_dim), device="cuda:0", generator=torch.Generator(device="cuda:0").manual_seed(5))).clamp_(-1, 1).contiguous()
+    b = BatchedEnv(cfg, num_envs=n, seed=21, auto_reset=True, gain_noise=0.1, ranges=ranges)
+    assert b.engine.query("rollout") == 1
+    for e in (a, b):
+        e.receive_user_command(cmd)
+        e.reset()
+    rows = []
+    for k in range(K):
+        s, te, tr, info = a.step(acts[k])
+        rows.append((s.clone(), te.clone(), tr.clone(), a.info_buf.clone()))
+    fix_a = a.solver_stats()["fixup_steps"]
+    S, TE, TR, INF = b.rollout(acts)
+    torch.cuda.synchronize()
+    sb = b.solver_stats()
+    assert sb["step_count"] == a.solver_stats()["step_count"] == n * (1 + K)
+    ref_s = torch.stack([r[0] for r in rows]); ref_te = torch.stack([r[1] for r in rows]); ref_tr = torch.stack([r[2] for r in rows])
+    ref_inf = torch.stack([r[3] for r in rows])
+    assert (ref_tr | ref_te).sum().item() >= n                     # every env ended an episode (fall or time limit) inside the table
+    same = ((S == ref_s).all(dim=2) & (INF == ref_inf).all(dim=2) & (TE == ref_te) & (TR == ref_tr)).all(dim=0)     # per env
+    odd = (~same).nonzero().flatten().tolist()
+    if fix_a == 0 and sb["fixup_steps"] == 0:
+        assert not odd
+    assert len(odd) <= max(2, n // 16), (len(odd), fix_a, sb["fixup_steps"])
+    for i in odd:                                                  # same trajectory up to rounding until the paths part
+        first = int((~((S[:, i] == ref_s[:, i]).all(dim=1))).nonzero()[0])
+        assert torch.equal(S[:first, i], ref_s[:first, i])
+        np.testing.assert_allclose(S[first, i].cpu().numpy(), ref_s[first, i].cpu().numpy(), rtol=0, atol=5e-3)
+    # the env keeps stepping afterwards, and its tensors hold the last row
+    assert torch.equal(b.state, S[-1]) and torch.equal(b.terminated, TE[-1])
+    b.step(acts[0])
+    torch.cuda.synchronize()
+    assert torch.isfinite(b.state).all()
+    a.close(); b.close()
+
+
+def test_rollout_is_refused_where_no_rollout_kernel_exists():
+    import torch
+    from cosim_amd.batched_env import BatchedEnv
+    from cosim_amd.config import make_config
+    cfg = make_config("humanoid_p_v0", terrain="stairs_up_hard", num_envs=8, seed=1)
+    env = BatchedEnv(cfg, num_envs=8, seed=1)
+    env.reset()
+    assert env.engine.query("rollout") == 0
+    with pytest.raises(ValueError):
+        env.rollout(torch.zeros((2, 8, env.action_dim), device="cuda:0"))
+    env.close()

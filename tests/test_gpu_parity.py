@@ -443,6 +443,47 @@ def test_more_contacts_than_the_fleet_kernel_holds_are_redone_not_dropped(parity
     assert untouched.mean() > 0.9                                # envs within the slots take the fleet kernel either way: same bits
 
 
+def test_rollout_hands_an_abandoned_env_to_the_large_capacity_kernel_for_the_rest_of_the_table(parity):
+    """cosim_rollout on drop poses: the fleet rollout kernel gives an env up at the first control step with more than 14 contacts
+    and the large-capacity rollout kernel carries it from THAT step to the end of the table.  Nothing is left out, and after
+    three control steps every env is where the oracle is."""
+    from oracle.oracle import Oracle
+    torch = parity["torch"]
+    o = Oracle(parity["cm"])
+    rng = np.random.default_rng(11)
+    K, P = 3, 96
+    q0s, acts, q1, v1, peak = [], np.zeros((K, P, 4)), [], [], []
+    for i in range(P):
+        q = parity["q0"].copy()
+        quat = rng.normal(size=4)
+        q[2] = rng.uniform(0.05, 0.25)
+        q[3:7] = quat / np.linalg.norm(quat)
+        q[7:] += rng.uniform(-0.3, 0.3, size=q.size - 7)
+        o.reset(q)
+        q0s.append(o.qpos.copy())
+        pk = 0
+        for t in range(K):
+            acts[t, i] = 0.3 * np.sin(0.3 * t + np.arange(4) + i)
+            o.control_step(acts[t, i])
+            pk = max(pk, o.ncon)
+        q1.append(o.qpos.copy()); v1.append(o.qvel.copy()); peak.append(pk)
+    q1, v1, peak = np.array(q1), np.array(v1), np.array(peak)
+    assert (peak > 14).sum() >= 20
+    env = _env(parity, P)
+    env.reset()
+    env.set_state(np.array(q0s), np.zeros((P, parity["cm"].blob.nv)), np.zeros((P, parity["cm"].blob.nv)))
+    S, TE, TR, INF = env.rollout(torch.tensor(acts, dtype=torch.float32, device=env.device))
+    d = env.get_data()
+    qp, qv = d.qpos.cpu().numpy().astype(np.float64), d.qvel.cpu().numpy().astype(np.float64)
+    st = env.solver_stats()
+    env.close()
+    assert st["dropped_contacts"] == 0 and st["nan_resets"] == 0 and st["max_contacts"] > 14
+    assert (peak > 14).sum() <= st["fixup_steps"] <= K * P                # every step from the abandoned one on is a large-capacity step
+    ev = np.abs(qv - v1).max(axis=1)
+    assert np.abs(qp - q1).max() < 1e-4, np.abs(qp - q1).max()
+    assert ev.max() < 1e-2 and np.median(ev) < 1e-3, (ev.max(), np.median(ev))
+
+
 def test_shard_invariance_and_auto_reset(parity):
     """N envs on one GPU == concatenation of two shards with the matching env_id0 (RNG keyed by global env id);
     auto-reset restarts an env inside the step that truncates it."""
