@@ -68,6 +68,7 @@ struct DevModel {
   LaneRec rec[64];
   // packed lower-triangle index -> (row, col)
   unsigned char tri_row[MAXTRI], tri_col[MAXTRI];
+  int g_hullmap[64];   // per geom: first cell of its hull's support map (cosim_hullmap.h) in KArgs::hull_cell, or -1 (no map: scan)
 };
 
 // wrapper layer, expanded per single-frame element

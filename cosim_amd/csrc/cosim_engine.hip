@@ -38,6 +38,9 @@ struct cosim_engine {
   DevObs* d_obs = nullptr;
   float *d_state = nullptr, *d_params = nullptr, *d_hull_vert = nullptr, *d_hfield = nullptr, *d_dbg = nullptr;
   int *d_hull_adr = nullptr, *d_hull_nbr = nullptr;
+  int2* d_hull_cell = nullptr;      // support maps of the hulls (cosim_hullmap.h)
+  float4* d_hull_cand = nullptr;
+  int hullmap_of_geom[64];          // what DevModel::g_hullmap holds while "support_map" is on
   unsigned* d_pairs = nullptr;   // robot-robot candidate pairs (geom1 | geom2 << 16)
   float4* d_gext = nullptr;      // per geom: MPR centre (body frame), raw sliding friction
   std::vector<float> h_params;
@@ -618,6 +621,32 @@ int cosim_create(const cosim_model_t* model, const float* hull_vert, const int* 
   else { delete e; return fail(COSIM_EINVAL, "cosim_create: no kernel instantiation for this (nv, nbody); add one in cosim_engine.hip"); }
   if (nv != 18 && model->neq > 0) { delete e; return fail(COSIM_EINVAL, "cosim_create: this robot's kernels keep no rows for connect equalities"); }
   if (model->ngeom > e->geom_stage) { delete e; return fail(COSIM_EINVAL, "cosim_create: more collision geoms than the plane kernel stages contacts for"); }
+  {
+    // support maps of the mesh geoms' hulls (geoms that share a hull slice share the map)
+    std::vector<int> cells;
+    std::vector<float> cand;
+    for (int g = 0; g < 64; g++) e->hullmap_of_geom[g] = -1;
+    for (int g = 0; g < model->ngeom; g++) {
+      if (model->geom_type[g] != CS_GEOM_MESH || model->geom_hullnum[g] < HM_MIN_VERTS || !hull_vert || !hull_adr || !hull_nbr) continue;
+      for (int h = 0; h < g; h++)
+        if (e->hullmap_of_geom[h] >= 0 && model->geom_hulladr[h] == model->geom_hulladr[g] && model->geom_hullnum[h] == model->geom_hullnum[g])
+          e->hullmap_of_geom[g] = e->hullmap_of_geom[h];
+      if (e->hullmap_of_geom[g] >= 0) continue;
+      const int adr = model->geom_hulladr[g], num = model->geom_hullnum[g];
+      if (adr < 0 || adr + num > model->nhullvert) { delete e; return fail(COSIM_EINVAL, "cosim_create: geom hull slice outside the hull vertex array"); }
+      for (int v = adr; v < adr + num; v++)
+        for (int k = hull_adr[v]; k < hull_adr[v + 1]; k++)
+          if (k < 0 || k >= model->nhulledge || hull_nbr[k] < 0 || hull_nbr[k] >= num) { delete e; return fail(COSIM_EINVAL, "cosim_create: hull neighbour graph out of range"); }
+      e->hullmap_of_geom[g] = (int)(cells.size() / 2);
+      build_support_map(hull_vert + 3 * (size_t)adr, num, hull_adr + adr, hull_nbr, cells, cand);
+    }
+    for (int g = 0; g < 64; g++) e->hm.g_hullmap[g] = e->hullmap_of_geom[g];
+    if (cells.empty()) { cells.assign(2, 0); cand.assign(4, 0.f); }
+    HIP_TRY(hipMalloc(&e->d_hull_cell, cells.size() * sizeof(int)));
+    HIP_TRY(hipMalloc(&e->d_hull_cand, cand.size() * sizeof(float)));
+    HIP_TRY(hipMemcpy(e->d_hull_cell, cells.data(), cells.size() * sizeof(int), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(e->d_hull_cand, cand.data(), cand.size() * sizeof(float), hipMemcpyHostToDevice));
+  }
   HIP_TRY(hipMalloc(&e->d_model, sizeof(DevModel)));
   HIP_TRY(hipMalloc(&e->d_obs, sizeof(DevObs)));
   HIP_TRY(hipMemcpy(e->d_model, &e->hm, sizeof(DevModel), hipMemcpyHostToDevice));
@@ -677,6 +706,7 @@ int cosim_destroy(cosim_engine_t* e) {
   hipSetDevice(e->device);
   hipFree(e->d_model); hipFree(e->d_obs); hipFree(e->d_state); hipFree(e->d_params); hipFree(e->d_dbg);
   hipFree(e->d_hull_vert); hipFree(e->d_hull_adr); hipFree(e->d_hull_nbr); hipFree(e->d_hfield);
+  hipFree(e->d_hull_cell); hipFree(e->d_hull_cand);
   hipFree(e->d_pairs); hipFree(e->d_gext); hipFree(e->d_ovf); hipFree(e->d_xcon); hipFree(e->d_xcnt); hipFree(e->d_xstate);
   for (hipEvent_t x : e->ev) hipEventDestroy(x);
   for (hipStream_t x : e->rstream) hipStreamDestroy(x);
@@ -759,6 +789,12 @@ int cosim_set_param(cosim_engine_t* e, const char* name, const float* host, int 
     return COSIM_OK;
   }
   else if (n == "narrow_occupancy") { e->narrow_occ = (int)host[0]; return COSIM_OK; }   // 2 | 3 | 4 (tuning)
+  else if (n == "support_map") {   // 0: mesh support queries scan the whole hull (A/B and tests); 1: through the support maps (default)
+    HIP_TRY(hipDeviceSynchronize());
+    for (int g = 0; g < 64; g++) e->hm.g_hullmap[g] = (int)host[0] != 0 ? e->hullmap_of_geom[g] : -1;
+    HIP_TRY(hipMemcpy(e->d_model, &e->hm, sizeof(DevModel), hipMemcpyHostToDevice));
+    return COSIM_OK;
+  }
   else if (n == "fixup") {   // 0: no fix-up launches (contacts beyond the fleet kernel's slots are left out and counted, as in round 2)
     if ((int)host[0] == 0) { e->launch_fix = nullptr; if (e->launch_roll_fix) { e->launch_roll = nullptr; e->launch_roll_fix = nullptr; } }
     return COSIM_OK;
@@ -806,6 +842,7 @@ static KArgs base_args(cosim_engine* e) {
   memset(&a, 0, sizeof a);
   a.dm = e->d_model; a.ob = e->d_obs; a.lay = e->lay; a.state = e->d_state; a.params = e->d_params;
   a.hull_vert = e->d_hull_vert; a.hull_adr = e->d_hull_adr; a.hull_nbr = e->d_hull_nbr; a.hfield = e->d_hfield;
+  a.hull_cell = e->d_hull_cell; a.hull_cand = e->d_hull_cand;
   a.pairs = e->d_pairs; a.gext = e->d_gext;
   a.n_envs = e->n_envs; a.seed_lo = (unsigned)e->seed; a.seed_hi = (unsigned)(e->seed >> 32); a.env_id0 = e->env_id0;
   a.tol32 = e->tol32; a.ls_scale = e->ls_scale; a.max_newton = e->max_newton; a.max_ls = e->max_ls; a.nsub_override = e->nsub_override; a.pair_coop = e->pair_coop; a.pair_boxbox = e->pair_boxbox;
@@ -912,6 +949,41 @@ int cosim_rollout(cosim_engine_t* e, int steps, const float* actions_dev, const 
     if (a.ovf) { e->launch_roll_fix(e, a, a.env_count, s); HIP_TRY(hipGetLastError()); }
   }
   if (nr > 1) { e->join_pending = true; return join_ranges(e, cs); }
+  return COSIM_OK;
+}
+
+// Test hook, host only (no GPU call): the support map of ONE hull (cosim_hullmap.h) against the full scan it replaces, with the
+// kernels' fp32 comparisons: for each of `ndir` directions (hull frame) the arg-max vertex through the map -> out_map_idx and by
+// scanning all n vertices -> out_scan_idx.  out_stats: [0] candidates in the table, [1] largest cell, [2] cells.
+int cosim_hull_support_check(const float* verts, int n, const int* adr, const int* nbr, const float* dirs, int ndir, int* out_map_idx,
+                             int* out_scan_idx, int* out_stats) {
+  if (!verts || !adr || !nbr || !dirs || !out_map_idx || !out_scan_idx || n < 1 || ndir < 0) return fail(COSIM_EINVAL, "cosim_hull_support_check: bad argument");
+  std::vector<int> cells;
+  std::vector<float> cand;
+  build_support_map(verts, n, adr, nbr, cells, cand);
+  int biggest = 0;
+  for (int c = 0; c < HM_CELLS; c++) biggest = cells[2 * c + 1] > biggest ? cells[2 * c + 1] : biggest;
+  if (out_stats) { out_stats[0] = (int)(cand.size() / 4); out_stats[1] = biggest; out_stats[2] = HM_CELLS; }
+  for (int d = 0; d < ndir; d++) {
+    const float* l = dirs + 3 * (size_t)d;
+    float best = -3.0e38f;
+    int bi = 0;
+    for (int i = 0; i < n; i++) {
+      const float t = l[0] * verts[3 * i] + l[1] * verts[3 * i + 1] + l[2] * verts[3 * i + 2];
+      if (t > best) { best = t; bi = i; }
+    }
+    out_scan_idx[d] = bi;
+    const int c = support_cell(l), start = cells[2 * c], count = cells[2 * c + 1];
+    best = -3.0e38f;
+    union { int i; float f; } ix;
+    ix.f = cand[4 * (size_t)start + 3];
+    for (int i = 0; i < count; i++) {
+      const float* x = &cand[4 * (size_t)(start + i)];
+      const float t = l[0] * x[0] + l[1] * x[1] + l[2] * x[2];
+      if (t > best) { best = t; ix.f = x[3]; }
+    }
+    out_map_idx[d] = ix.i;
+  }
   return COSIM_OK;
 }
 
@@ -1079,6 +1151,25 @@ int cosim_profile_step(cosim_engine_t* e, const float* actions_dev, const float*
   unsigned long long raw[32];
   HIP_TRY(hipMemcpy(raw, e->d_dbg, sizeof raw, hipMemcpyDeviceToHost));
   for (int i = 0; i < 32; i++) cycles_out16[i] = (double)raw[i] / (double)(e->n_envs / e->epw);   // per wave
+  return COSIM_OK;
+}
+
+// Test hook: support points of mesh geom `geom` at identity pose for n_dirs directions, from the device's own support routines:
+// out [n_dirs][6] = the lane-parallel routine's point, then the wave-cooperative routine's.  use_map 0: full scans of the hull.
+int cosim_debug_support(cosim_engine_t* e, int geom, const float* dirs_host, int n_dirs, float* out_host, int use_map) {
+  if (!e || !dirs_host || !out_host || n_dirs < 1 || geom < 0 || geom >= e->hm.ngeom) return fail(COSIM_EINVAL, "cosim_debug_support: bad argument");
+  if (e->hm.rec[geom].g_type != CS_GEOM_MESH) return fail(COSIM_EINVAL, "cosim_debug_support: not a mesh geom");
+  HIP_TRY(hipSetDevice(e->device));
+  float *d_dirs = nullptr, *d_out = nullptr;
+  HIP_TRY(hipMalloc(&d_dirs, (size_t)n_dirs * 3 * sizeof(float)));
+  HIP_TRY(hipMalloc(&d_out, (size_t)n_dirs * 6 * sizeof(float)));
+  HIP_TRY(hipMemcpy(d_dirs, dirs_host, (size_t)n_dirs * 3 * sizeof(float), hipMemcpyHostToDevice));
+  const HullGraph H{e->d_hull_vert, e->d_hull_adr, e->d_hull_nbr, e->d_hull_cell, e->d_hull_cand};
+  hipLaunchKernelGGL(support_probe_kernel, dim3((n_dirs + 63) / 64), dim3(64), 0, 0, e->d_model, H, geom, d_dirs, n_dirs, d_out, use_map);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpy(out_host, d_out, (size_t)n_dirs * 6 * sizeof(float), hipMemcpyDeviceToHost));
+  hipFree(d_dirs); hipFree(d_out);
   return COSIM_OK;
 }
 

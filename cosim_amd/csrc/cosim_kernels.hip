@@ -15,6 +15,7 @@
 //     v_readlane broadcasts; reductions use DPP row operations;
 //   * per-env state is one contiguous HBM record, read once and written once per control step.
 #include "cosim_dev.h"
+#include "cosim_hullmap.h"
 
 namespace cosim {
 
@@ -43,6 +44,8 @@ struct KArgs {
   const float* hull_vert;
   const int* hull_adr;
   const int* hull_nbr;
+  const int2* hull_cell;     // support maps (cosim_hullmap.h): (start, count) per cell, candidates (x, y, z, vertex index)
+  const float4* hull_cand;
   const float* hfield;
   const unsigned* pairs;  // robot-robot candidate pairs: geom1 | geom2 << 16
   const float4* gext;     // per geom: MPR centre (body frame) xyz, raw sliding friction w
@@ -1032,7 +1035,7 @@ __device__ __forceinline__ void env_body(KArgsP kargs_p, const int env, typename
       // =========================================================== collision: ground (plane or heightfield) vs robot geoms
       int ncon = 0;
       int npc = 0;   // CT: robot-robot contacts (slots of their own, dense rows); otherwise they follow the ground contacts in ncon
-      const HullGraph HG{A.hull_vert, A.hull_adr, A.hull_nbr};
+      const HullGraph HG{A.hull_vert, A.hull_adr, A.hull_nbr, A.hull_cell, A.hull_cand};
       const float4* const gext_ = A.gext;   // (locals, so that the lambdas below do not capture the argument-block pointer)
       const float* const hfdata_ = A.hfield;
       float* const xcon_ = KM == 1 ? A.xcon + (size_t)env * (XG * XC * 8) : nullptr;   // narrowphase kernel: this env's contact records
@@ -1046,7 +1049,7 @@ __device__ __forceinline__ void env_body(KArgsP kargs_p, const int env, typename
         float v[3];
         qrot(v, bq, cl);
         for (int k = 0; k < 3; k++) o.center[k] = S.xpos[gb][k] + v[k];
-        o.kind = G.g_type; o.adr = G.g_hulladr; o.num = G.g_hullnum;
+        o.kind = G.g_type; o.adr = G.g_hulladr; o.num = G.g_hullnum; o.map = dm.g_hullmap[g];
         for (int k = 0; k < 3; k++) o.size[k] = G.g_size[k];
         if (G.g_type == CS_GEOM_MESH) {
           for (int k = 0; k < 3; k++) o.pos[k] = S.xpos[gb][k];
@@ -1549,7 +1552,19 @@ __device__ __forceinline__ void env_body(KArgsP kargs_p, const int env, typename
           const float offn = n[0] * (gxp[0] - P0[0]) + n[1] * (gxp[1] - P0[1]) + n[2] * (gxp[2] - P0[2]);
           float best = 3.0e38f;
           int besti = 0x7fffffff;
-          {
+          const int hmap = dm.g_hullmap[g];
+          if (hmap >= 0) {
+            // support map (cosim_hullmap.h): the lowest vertex is the support point along -n; the candidates of that cell, one per lane
+            const float dn[3] = {-lnv[0], -lnv[1], -lnv[2]};
+            const int2 ce = A.hull_cell[hmap + support_cell(dn)];   // (uniform over the env's LW lanes)
+            const int cn = ce.y;
+            const float4* cp = A.hull_cand + ce.x;
+            for (int i0 = 0; i0 < cn; i0 += LW) {
+              const float4 x = cp[min(i0 + ln, cn - 1)];
+              const float dist = offn + hull_dot(lnv, x);
+              if (i0 + ln < cn && dist < best) { best = dist; besti = __float_as_int(x.w); }
+            }
+          } else {
             // four vertices per lane in flight per trip (16 bytes per vertex: one load each)
             const float4* hv = reinterpret_cast<const float4*>(A.hull_vert) + adr;
             for (int i0 = 0; i0 < num; i0 += 4 * LW) {
@@ -1559,7 +1574,7 @@ __device__ __forceinline__ void env_body(KArgsP kargs_p, const int env, typename
 #pragma unroll
               for (int k = 0; k < 4; k++) {
                 const int i = i0 + ln + LW * k;
-                const float dist = offn + lnv[0] * x[k].x + lnv[1] * x[k].y + lnv[2] * x[k].z;
+                const float dist = offn + hull_dot(lnv, x[k]);
                 if (i < num && dist < best) { best = dist; besti = i; }
               }
             }
@@ -1580,7 +1595,7 @@ __device__ __forceinline__ void env_body(KArgsP kargs_p, const int env, typename
               const int i = cand == 0 ? bi : A.hull_nbr[lo + cand - 1];
               const float4 v4 = reinterpret_cast<const float4*>(A.hull_vert)[adr + i];
               const float v[3] = {v4.x, v4.y, v4.z};
-              dist = offn + lnv[0] * v[0] + lnv[1] * v[1] + lnv[2] * v[2];
+              dist = offn + hull_dot(lnv, v4);
               okc = !(dist > gmargin);
               const float w[3] = {m[0] * v[0] + m[1] * v[1] + m[2] * v[2], m[3] * v[0] + m[4] * v[1] + m[5] * v[2], m[6] * v[0] + m[7] * v[1] + m[8] * v[2]};
               for (int k = 0; k < 3; k++) cpw[k] = gxp[k] + w[k] - n[k] * dist * 0.5f;
@@ -2912,5 +2927,31 @@ __global__ __launch_bounds__(64, 4) void env_fixup_kernel(KArgs kernarg_block) {
 }
 #undef A
 #undef KARGS_FENCE
+
+
+// Diagnostic / test kernel: the support function of mesh geom `geom` (identity pose) for n directions, through every code path that
+// answers such queries: [0] lane-parallel (one direction per lane), [1] wave-cooperative (one direction per wave at a time), [2..7] the
+// six-direction box routine's hi/lo corners for the pose given by quaternion dirs-as-axis (only for the first direction of each wave).
+__global__ void support_probe_kernel(const DevModel* dmp, HullGraph H, int geom, const float* dirs, int n, float* out, int use_map) {
+  const int ln = threadIdx.x, i = blockIdx.x * 64 + ln;
+  CObj o;
+  o.kind = CS_GEOM_MESH;
+  for (int k = 0; k < 3; k++) { o.pos[k] = 0.f; o.size[k] = 0.f; o.center[k] = 0.f; }
+  o.q[0] = 1.f; o.q[1] = o.q[2] = o.q[3] = 0.f;
+  o.adr = dmp->rec[geom].g_hulladr; o.num = dmp->rec[geom].g_hullnum; o.map = use_map ? dmp->g_hullmap[geom] : -1;
+  float d[3] = {1.f, 0.f, 0.f};
+  if (i < n) for (int k = 0; k < 3; k++) d[k] = dirs[3 * (size_t)i + k];
+  float p[3];
+  cobj_support<GT_MESH, false>(o, H, d, p, ln);
+  if (i < n) for (int k = 0; k < 3; k++) out[6 * (size_t)i + k] = p[k];
+  for (int j = 0; j < 64; j++) {
+    const int ij = blockIdx.x * 64 + j;
+    if (ij >= n) break;
+    const float dj[3] = {rl(d[0], j), rl(d[1], j), rl(d[2], j)};
+    float pj[3];
+    cobj_support<GT_MESH, true>(o, H, dj, pj, ln);
+    if (ln == 0) for (int k = 0; k < 3; k++) out[6 * (size_t)ij + 3 + k] = pj[k];
+  }
+}
 
 }  // namespace cosim

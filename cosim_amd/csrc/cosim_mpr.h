@@ -25,15 +25,19 @@ struct CObj {            // one convex geom, world pose
   float pos[3], q[4];    // primitive: geom frame; mesh: body frame (hull vertices are stored in body coordinates)
   float size[3];
   int adr, num;          // mesh: slice of the hull vertex array
+  int map;               // mesh: first cell of the hull's support map (cosim_hullmap.h), or -1: scan the hull
   float center[3];       // mjccd_center
 };
 // hull arrays (vertices in body coordinates; CSR neighbour graph, used by the plane-hull routine)
-struct HullGraph { const float* vert; const int* adr; const int* nbr; };
+struct HullGraph { const float* vert; const int* adr; const int* nbr; const int2* cell; const float4* cand; };
 typedef double real;   // the portal arithmetic runs in fp64 (ill-conditioned for edge contacts); supports are fp32
 __device__ __forceinline__ real mpr_dot(const real* a, const real* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
 __device__ __forceinline__ void mpr_cross(real* r, const real* a, const real* b) {
   r[0] = a[1] * b[2] - a[2] * b[1]; r[1] = a[2] * b[0] - a[0] * b[2]; r[2] = a[0] * b[1] - a[1] * b[0];
 }
+// dir . vertex of every hull support query, one fixed sequence of roundings: the scans and the support-map walks must agree on
+// near-ties, and the compiler contracts a plain a*x + b*y + c*z differently from loop to loop
+__device__ __forceinline__ float hull_dot(const float* l, const float4& x) { return __builtin_fmaf(l[2], x.z, __builtin_fmaf(l[1], x.y, l[0] * x.x)); }
 struct MprSup { real v[3]; float v1[3]; };  // Minkowski-difference support point v = s1(dir) - s2(-dir) (exact in fp64) and its fp32 s1 part
 
 __device__ __forceinline__ bool mpr_zero(real x) { return fabs(x) < MPR_EPS; }
@@ -67,9 +71,10 @@ __device__ __forceinline__ void cobj_support(const CObj& o, const HullGraph& H, 
     // trip (a dependent load per vertex made this loop cost ~600 cycles per vertex).
     // (Hill climbing on the neighbour graph from a direction-indexed seed was measured 2x slower here: its dependent,
     // lane-divergent loads do not overlap.)
+    // A hull with a support map (cosim_hullmap.h) is not scanned: the lane walks the candidates of its direction's cell.
     float best = -3.0e38f;
     int bi = 0;
-    bool pending = true;
+    bool pending = o.map < 0;
     for (unsigned long long pm = __ballot(pending); pm != 0ull; pm = __ballot(pending)) {
       const int src = __builtin_ctzll(pm);   // a lane that still waits: its hull is served now
       const int adr_u = __builtin_amdgcn_readlane(o.adr, src), num_u = __builtin_amdgcn_readlane(o.num, src);
@@ -81,13 +86,29 @@ __device__ __forceinline__ void cobj_support(const CObj& o, const HullGraph& H, 
         for (int k = 0; k < 4; k++) x[k] = v0[min(i + k, num_u - 1)];
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-          const float t = l[0] * x[k].x + l[1] * x[k].y + l[2] * x[k].z;
+          const float t = hull_dot(l, x[k]);
           if (mine && i + k < num_u && t > best) { best = t; bi = i + k; }
         }
       }
       if (mine) pending = false;
     }
-    const float4 v = reinterpret_cast<const float4*>(hull)[o.adr + bi];
+    float4 v;
+    if (o.map < 0) v = reinterpret_cast<const float4*>(hull)[o.adr + bi];
+    else {
+      const int2 ce = H.cell[o.map + support_cell(l)];
+      const float4* cp = H.cand + ce.x;
+      v = cp[0];
+      for (int i = 0; i < ce.y; i += 4) {
+        float4 x[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) x[k] = cp[min(i + k, ce.y - 1)];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          const float t = hull_dot(l, x[k]);
+          if (i + k < ce.y && t > best) { best = t; v = x[k]; }
+        }
+      }
+    }
     r[0] = v.x; r[1] = v.y; r[2] = v.z;
   } else if (COOP && (GTM & GT_MESH) && o.kind == CS_GEOM_MESH) {
     // all 64 lanes share one scan over the hull (16 bytes per vertex: one load each).  COOP_K vertices per lane are in flight per trip (a dependent trip per vertex made a 696-vertex
@@ -98,6 +119,19 @@ __device__ __forceinline__ void cobj_support(const CObj& o, const HullGraph& H, 
     const float4* v0 = reinterpret_cast<const float4*>(hull) + __builtin_amdgcn_readfirstlane(o.adr);
     float best = -3.0e38f, bx = 0.f, by = 0.f, bz = 0.f;
     int besti = 0x7fffffff;
+    const int map = __builtin_amdgcn_readfirstlane(o.map);
+    if (map >= 0) {
+      // support map: the candidates of the direction's cell, one per lane (a few; a cell facing a flat side of the hull holds up
+      // to ~90); besti is the vertex's index in the hull, so ties fall like in the scan
+      const int2 ce = H.cell[map + __builtin_amdgcn_readfirstlane(support_cell(l))];
+      const int cn = __builtin_amdgcn_readfirstlane(ce.y);
+      const float4* cp = H.cand + __builtin_amdgcn_readfirstlane(ce.x);
+      for (int i0 = 0; i0 < cn; i0 += 64) {
+        const float4 x = cp[min(i0 + ln, cn - 1)];
+        const float t = hull_dot(l, x);
+        if (i0 + ln < cn && t > best) { best = t; besti = __float_as_int(x.w); bx = x.x; by = x.y; bz = x.z; }
+      }
+    } else
     for (int i0 = 0; i0 < num; i0 += 64 * COOP_K) {
       float4 x[COOP_K];
 #pragma unroll
@@ -105,7 +139,7 @@ __device__ __forceinline__ void cobj_support(const CObj& o, const HullGraph& H, 
 #pragma unroll
       for (int k = 0; k < COOP_K; k++) {
         const int i = i0 + ln + 64 * k;
-        const float t = l[0] * x[k].x + l[1] * x[k].y + l[2] * x[k].z;
+        const float t = hull_dot(l, x[k]);
         if (i < num && t > best) { best = t; besti = i; bx = x[k].x; by = x[k].y; bz = x[k].z; }
       }
     }
@@ -114,7 +148,10 @@ __device__ __forceinline__ void cobj_support(const CObj& o, const HullGraph& H, 
     const float bmax = -wave_min(-best);
     const unsigned long long tm = __ballot(best == bmax);
     int src = __builtin_ctzll(tm);
-    if (tm & (tm - 1)) src = ((int)wave_min(best == bmax ? (float)besti : 3.0e38f)) & 63;
+    if (tm & (tm - 1)) {   // (a scanned vertex i lives in lane i & 63; a support-map candidate wherever its list position put it)
+      const float imin = wave_min(best == bmax ? (float)besti : 3.0e38f);
+      src = __builtin_ctzll(__ballot(best == bmax && (float)besti == imin));
+    }
     src = __builtin_amdgcn_readfirstlane(src);
     r[0] = rl(bx, src); r[1] = rl(by, src); r[2] = rl(bz, src);
   } else if ((GTM & GT_SPHERE) && o.kind == CS_GEOM_SPHERE) {
@@ -148,6 +185,30 @@ __device__ __forceinline__ void cobj_box_coop(const CObj& o, const HullGraph& H,
   int besti[6];
 #pragma unroll
   for (int s = 0; s < 6; s++) { best[s] = -3.0e38f; besti[s] = 0x7fffffff; bv[s][0] = bv[s][1] = bv[s][2] = 0.f; }
+  const int map = __builtin_amdgcn_readfirstlane(o.map);
+  if (map >= 0) {
+    // support map: six cells, their candidates one per lane, all six loads in flight together
+    int cb[6], cn[6], nmax = 0;
+#pragma unroll
+    for (int s = 0; s < 6; s++) {
+      const float d[3] = {(s & 1) ? -l[s >> 1][0] : l[s >> 1][0], (s & 1) ? -l[s >> 1][1] : l[s >> 1][1], (s & 1) ? -l[s >> 1][2] : l[s >> 1][2]};
+      const int2 ce = H.cell[map + __builtin_amdgcn_readfirstlane(support_cell(d))];
+      cb[s] = __builtin_amdgcn_readfirstlane(ce.x); cn[s] = __builtin_amdgcn_readfirstlane(ce.y);
+      nmax = max(nmax, cn[s]);
+    }
+    for (int i0 = 0; i0 < nmax; i0 += 64) {
+      float4 x[6];
+#pragma unroll
+      for (int s = 0; s < 6; s++) x[s] = H.cand[cb[s] + min(i0 + ln, cn[s] - 1)];
+#pragma unroll
+      for (int s = 0; s < 6; s++) {
+        const int a = s >> 1;
+        const float t0 = hull_dot(l[a], x[s]);
+        const float t = (s & 1) ? -t0 : t0;
+        if (i0 + ln < cn[s] && t > best[s]) { best[s] = t; besti[s] = __float_as_int(x[s].w); bv[s][0] = x[s].x; bv[s][1] = x[s].y; bv[s][2] = x[s].z; }
+      }
+    }
+  } else
   for (int i0 = 0; i0 < num; i0 += 64 * 4) {
     float4 x[4];
 #pragma unroll
@@ -158,7 +219,7 @@ __device__ __forceinline__ void cobj_box_coop(const CObj& o, const HullGraph& H,
 #pragma unroll
       for (int a = 0; a < 3; a++) {
         // the query along -e_a rotates to exactly -l[a] (qrot is odd in its vector argument), whose dot products are exactly -t
-        const float t = l[a][0] * x[k].x + l[a][1] * x[k].y + l[a][2] * x[k].z;
+        const float t = hull_dot(l[a], x[k]);
         if (i < num && t > best[2 * a]) { best[2 * a] = t; besti[2 * a] = i; bv[2 * a][0] = x[k].x; bv[2 * a][1] = x[k].y; bv[2 * a][2] = x[k].z; }
         const float u = -t;
         if (i < num && u > best[2 * a + 1]) { best[2 * a + 1] = u; besti[2 * a + 1] = i; bv[2 * a + 1][0] = x[k].x; bv[2 * a + 1][1] = x[k].y; bv[2 * a + 1][2] = x[k].z; }
@@ -170,7 +231,10 @@ __device__ __forceinline__ void cobj_box_coop(const CObj& o, const HullGraph& H,
     const float bmax = -wave_min(-best[s]);
     const unsigned long long tm = __ballot(best[s] == bmax);
     int src = __builtin_ctzll(tm);
-    if (tm & (tm - 1)) src = ((int)wave_min(best[s] == bmax ? (float)besti[s] : 3.0e38f)) & 63;
+    if (tm & (tm - 1)) {
+      const float imin = wave_min(best[s] == bmax ? (float)besti[s] : 3.0e38f);
+      src = __builtin_ctzll(__ballot(best[s] == bmax && (float)besti[s] == imin));
+    }
     src = __builtin_amdgcn_readfirstlane(src);
     const float r[3] = {rl(bv[s][0], src), rl(bv[s][1], src), rl(bv[s][2], src)};
     float w[3];

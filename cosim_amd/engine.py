@@ -92,6 +92,8 @@ def load_library():
     L.cosim_step.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp]
     L.cosim_step_range.argtypes = [vp, ci, ci, vp, vp, vp, vp, vp, vp, vp]
     L.cosim_join.argtypes = [vp, vp]
+    L.cosim_debug_support.argtypes = [vp, ci, vp, ci, vp, ci]
+    L.cosim_hull_support_check.argtypes = [vp, ci, vp, vp, vp, ci, vp, vp, vp]
     L.cosim_rollout.argtypes = [vp, ci, vp, vp, vp, vp, vp, vp, vp]
     L.cosim_range.argtypes = [vp, ci, ctypes.POINTER(ci), ctypes.POINTER(ci), ctypes.POINTER(vp)]
     L.cosim_range_mark.argtypes = [vp, ci]
@@ -117,7 +119,7 @@ def load_library():
 
 
 EXPORTS = ["cosim_create", "cosim_destroy", "cosim_query", "cosim_set_param", "cosim_reset", "cosim_step", "cosim_step_range", "cosim_get",
-           "cosim_join", "cosim_range", "cosim_range_mark", "cosim_debug_counters", "cosim_rollout",
+           "cosim_join", "cosim_range", "cosim_range_mark", "cosim_debug_counters", "cosim_rollout", "cosim_hull_support_check", "cosim_debug_support",
            "cosim_set", "cosim_event_push", "cosim_debug_forward", "cosim_kernel_time", "cosim_set_timing",
            "cosim_profile_step", "cosim_mlp_forward", "cosim_lstm_cell", "cosim_fleet_stats", "cosim_fleet_hist", "cosim_last_error", "cosim_model_sizeof", "cosim_obs_config_sizeof"]
 

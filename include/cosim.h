@@ -92,7 +92,9 @@ int cosim_query(const cosim_engine_t* e, const char* name);
  * range stream before it blocks, default 4, 0 = unbounded: deep queues step slower on this runtime), "split" (heightfield kernels that have the two-kernel pipeline -- humanoid_p_v0:
  * the prism walk in a kernel of its own, "narrow_waves" (default 4) waves per env, and the solver one substep per launch; 0 goes back
  * to the fused kernel), "fixup" (0 switches the
- * large-capacity fix-up launches off: contacts beyond the fleet kernel's slots are then left out and counted).
+ * large-capacity fix-up launches off: contacts beyond the fleet kernel's slots are then left out and counted), "support_map" (1,
+ * default: support queries on mesh geoms with 32 or more hull vertices go through the hull's support map -- the few vertices that can
+ * win in the direction's cube-map cell, same arg max as the scan; 0: every query scans the whole hull, for A/B runs and tests).
  * cosim_query additionally answers "contact_slots" / "pair_slots" (capacity of the selected kernel variant: heightfields with cells
  * of 10 cm or more select the 48-slot variants of flamingo_light_v1 / w4_p_v2), "fixup_contact_slots" (capacity of the kernel that
  * redoes a control step whose contacts did not fit; 0: this model / terrain has none), "ranges" and "lds_bytes". */
@@ -129,6 +131,16 @@ int cosim_step(cosim_engine_t* e, const float* actions_dev, const float* command
  * cosim_query "rollout" is 1; the caller's stream waits for the whole rollout on return. */
 int cosim_rollout(cosim_engine_t* e, int steps, const float* actions_dev, const float* commands_dev, float* state_out_dev, uint8_t* terminated_dev,
                   uint8_t* truncated_dev, float* info_out_dev, void* stream);
+/* Test hook, host only (no GPU call): the support map the engine builds for a mesh geom's convex hull (csrc/cosim_hullmap.h: per cell
+ * of a cube map of directions, the vertices that can be the support point somewhere in the cell) against the full scan over the hull
+ * that the reference's support function performs (mjc_support -> arg max of dir . vertex).  verts [n][3]; adr [n + 1] / nbr: CSR
+ * neighbour graph of the hull, ids local to the hull; dirs [ndir][3] in the hull's frame.  out_map_idx / out_scan_idx [ndir]: the
+ * arg-max vertex through the map / by scanning; out_stats[3] (may be NULL): candidates in the table, largest cell, cells. */
+int cosim_hull_support_check(const float* verts, int n, const int* adr, const int* nbr, const float* dirs, int ndir, int* out_map_idx,
+                             int* out_scan_idx, int* out_stats);
+/* Test hook (GPU): the device's own support routines on mesh geom `geom` at identity pose, for n_dirs directions (host float[n][3]):
+ * out_host [n_dirs][6] = support point from the lane-parallel routine, then from the wave-cooperative one.  use_map 0: full scans. */
+int cosim_debug_support(cosim_engine_t* e, int geom, const float* dirs_host, int n_dirs, float* out_host, int use_map);
 int cosim_join(cosim_engine_t* e, void* stream);
 /* Range i of "ranges": its first env, env count and stream (hipStream_t; NULL when ranges == 1).  Work enqueued on that stream from
  * outside (a per-range policy, a reporter reduction) is ordered with the range's steps; cosim_range_mark(i) re-arms the range's

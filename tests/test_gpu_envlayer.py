@@ -526,3 +526,73 @@ def test_rollout_is_refused_where_no_rollout_kernel_exists():
     with pytest.raises(ValueError):
         env.rollout(torch.zeros((2, 8, env.action_dim), device="cuda:0"))
     env.close()
+
+
+@pytest.mark.parametrize("env_id,terrain", [("w4_p_v2", "rocky_hard"), ("flamingo_p_v3", "flat"), ("w4_p_v2", "flat"),
+                                            ("humanoid_p_v0", "stairs_up_hard"), ("flamingo_p_v3", "rocky_easy")])
+def test_support_maps_leave_every_bit_of_the_fleet_as_the_hull_scans_do(env_id, terrain):
+    """Mesh support queries through the hulls' support maps (csrc/cosim_hullmap.h) against full scans of the hulls (what the
+    reference's mjc_support does): the same vertex every time, so the same contacts and the same fleet, bit for bit -- prism walk,
+    cooperative hull walk, plane-hull routine and robot-robot pairs included."""
+    import torch
+    from cosim_amd.batched_env import BatchedEnv
+    from cosim_amd.config import make_config
+    n, K = 128, 60
+    cfg = make_config(env_id, terrain=terrain, num_envs=n, seed=33)
+    outs = []
+    for use_map in (1.0, 0.0):
+        env = BatchedEnv(cfg, num_envs=n, seed=33, auto_reset=True, gain_noise=0.1)
+        env.engine.set_param("support_map", np.array([use_map], dtype=np.float32))
+        acts = (0.5 * torch.randn((K, n, env.action_dim), device="cuda:0", generator=torch.Generator(device="cuda:0").manual_seed(8))).clamp_(-1, 1)
+        env.reset()
+        states = []
+        for k in range(K):
+            s, te, tr, _ = env.step(acts[k])
+            states.append(s.clone())
+        d = env.get_data()
+        st = env.solver_stats()
+        outs.append((torch.stack(states), d.qpos.clone(), d.qvel.clone(), st["rows"], st["newton_iters"]))
+        env.close()
+    assert outs[0][3] == outs[1][3] and outs[0][4] == outs[1][4]
+    assert outs[0][3] > 0
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[0][2], outs[1][2])
+
+
+@pytest.mark.parametrize("robot", ["humanoid_p_v0", "w4_p_v2", "flamingo_p_v3"])
+def test_device_support_routines_agree_map_scan_lane_parallel_and_cooperative(robot):
+    """The device's own support routines (cosim_debug_support) on every mesh hull: through the support map and by scanning the
+    hull, lane-parallel and wave-cooperative -- four ways, one vertex, the one a host-side scan with the same roundings finds.
+    Directions include near-ties (within 1e-4 of a hull face normal's axis), where a different rounding sequence per loop used to
+    break the tie differently."""
+    from cosim_amd.batched_env import BatchedEnv
+    from cosim_amd.config import make_config
+    from cosim_amd.model import get_field
+    env = BatchedEnv(make_config(robot, num_envs=2, seed=1), num_envs=2, seed=1)
+    b = env.cm.blob
+    gnum = np.array(get_field(b, "geom_hullnum")[:b.ngeom]); gadr = np.array(get_field(b, "geom_hulladr")[:b.ngeom])
+    rng = np.random.default_rng(0)
+    checked = 0
+    for g in range(b.ngeom):
+        if gnum[g] < 32:
+            continue
+        V = env.cm.hull_vert[gadr[g]:gadr[g] + gnum[g]].astype(np.float32)
+        D = rng.normal(size=(12000, 3))
+        D[:2000, :2] *= 1e-4
+        D[2000:4000, 1:] *= 1e-4
+        D[4000:6000, ::2] *= 1e-4
+        D = np.ascontiguousarray(D / np.linalg.norm(D, axis=1)[:, None], dtype=np.float32)
+        outs = []
+        for use_map in (1, 0):
+            o = np.zeros((len(D), 6), dtype=np.float32)
+            env.engine._check(env.engine.L.cosim_debug_support(env.engine.h, g, D.ctypes.data, len(D), o.ctypes.data, use_map))
+            outs.append(o)
+        assert np.array_equal(outs[0], outs[1])
+        assert np.array_equal(outs[0][:, :3], outs[0][:, 3:])
+        # host twin of hull_dot: fma(l2, z, fma(l1, y, l0 * x)) in fp32, emulated in fp64 (exact products and sums, rounded to fp32 each step)
+        t = (D[:, 0:1].astype(np.float64) * V[None, :, 0]).astype(np.float32)
+        t = (D[:, 1:2].astype(np.float64) * V[None, :, 1] + t).astype(np.float32)
+        t = (D[:, 2:3].astype(np.float64) * V[None, :, 2] + t).astype(np.float32)
+        assert np.array_equal(outs[0][:, :3], V[t.argmax(1)])
+        checked += 1
+    assert checked >= 2
+    env.close()

@@ -333,3 +333,47 @@ def test_one_env_info_stream_is_accepted_by_the_reference_reporter(tmp_path):
         rep.write_info(one)
     rep.generate_report()
     assert os.path.getsize(tmp_path / "report.pdf") > 10000
+
+
+@pytest.mark.parametrize("robot", ["w4_p_v2", "flamingo_p_v3", "humanoid_p_v0"])
+def test_hull_support_map_returns_the_vertex_of_the_full_scan(robot):
+    """The reference's support function for a mesh geom scans every hull vertex (mjc_support: arg max of dir . vertex).  The engine
+    looks the direction up in a cube map of candidate lists instead (csrc/cosim_hullmap.h); the answer must be the vertex the scan
+    finds, ties included (lowest index).  Host-only hook, every hull the robots carry; random directions plus the ones that make
+    ties or sit on cell borders: face normals of the hull, the coordinate axes, cube-map cell corners, and nudged copies."""
+    from scipy.spatial import ConvexHull
+    from cosim_amd.model import get_field
+    L = load_library()
+    cm = compile_model(make_config(robot, num_envs=1))
+    b = cm.blob
+    gadr = np.array(get_field(b, "geom_hulladr")[:b.ngeom]); gnum = np.array(get_field(b, "geom_hullnum")[:b.ngeom])
+    rng = np.random.default_rng(4)
+    seen, checked = set(), 0
+    for g in range(b.ngeom):
+        if gnum[g] < 32 or (gadr[g], gnum[g]) in seen:
+            continue
+        seen.add((gadr[g], gnum[g]))
+        V = np.ascontiguousarray(cm.hull_vert[gadr[g]:gadr[g] + gnum[g]], dtype=np.float32)
+        adr = np.ascontiguousarray(cm.hull_adr[gadr[g]:gadr[g] + gnum[g] + 1], dtype=np.int32)
+        nbr = np.ascontiguousarray(cm.hull_nbr, dtype=np.int32)
+        D = [rng.normal(size=(100000, 3))]
+        D.append(ConvexHull(V.astype(np.float64)).equations[:, :3])                          # face normals: whole faces tie
+        D.append(np.concatenate([np.eye(3), -np.eye(3)]))
+        R = 16
+        t = -1.0 + 2.0 * np.arange(R + 1) / R
+        uu, vv = np.meshgrid(t, t, indexing="ij")
+        for a in range(3):
+            for s in (1.0, -1.0):
+                P = np.zeros((uu.size, 3)); P[:, a] = s; P[:, (a + 1) % 3] = uu.ravel(); P[:, (a + 2) % 3] = vv.ravel()
+                D.append(P)                                                                   # cell corners and borders
+        D = np.concatenate(D)
+        D = np.concatenate([D, D + 1e-6 * rng.normal(size=D.shape), D * 1e-3, V.astype(np.float64) - V.mean(0)])
+        D = np.ascontiguousarray(D / np.maximum(np.linalg.norm(D, axis=1), 1e-30)[:, None] * rng.uniform(0.5, 2.0, size=(len(D), 1)), dtype=np.float32)
+        mi = np.zeros(len(D), dtype=np.int32); si = np.zeros(len(D), dtype=np.int32); st = np.zeros(3, dtype=np.int32)
+        rc = L.cosim_hull_support_check(V.ctypes.data, len(V), adr.ctypes.data, nbr.ctypes.data, D.ctypes.data, len(D), mi.ctypes.data,
+                                        si.ctypes.data, st.ctypes.data)
+        assert rc == 0
+        assert np.array_equal(mi, si), (robot, g, int((mi != si).sum()))
+        assert st[2] == 6 * R * R and st[0] / st[2] < 12.0 and st[1] < len(V), st         # a handful of candidates per cell
+        checked += 1
+    assert checked >= 2
