@@ -36,7 +36,7 @@ struct cosim_engine {
   Layout lay;
   DevModel* d_model = nullptr;
   DevObs* d_obs = nullptr;
-  float *d_state = nullptr, *d_params = nullptr, *d_hull_vert = nullptr, *d_hfield = nullptr, *d_dbg = nullptr;
+  float *d_state = nullptr, *d_params = nullptr, *d_hull_vert = nullptr, *d_hfield = nullptr, *d_hfield_mip = nullptr, *d_dbg = nullptr;
   int *d_hull_adr = nullptr, *d_hull_nbr = nullptr;
   int2* d_hull_cell = nullptr;      // support maps of the hulls (cosim_hullmap.h)
   float4* d_hull_cand = nullptr;
@@ -53,6 +53,7 @@ struct cosim_engine {
   int max_ls = 24;
   int nsub_override = 0;
   int pair_coop = 1;
+  int block_cull = 1;
   int pair_boxbox = 1;
   int prio[4] = {3, 0, 2, 4};   // wave priority by solver lag (see the kernel): usual iterations per substep, lag thresholds
   // timing
@@ -694,6 +695,17 @@ int cosim_create(const cosim_model_t* model, const float* hull_vert, const int* 
     size_t nh = (size_t)model->hfield_nrow * model->hfield_ncol;
     HIP_TRY(hipMalloc(&e->d_hfield, nh * sizeof(float)));
     HIP_TRY(hipMemcpy(e->d_hfield, hfield, nh * sizeof(float), hipMemcpyHostToDevice));
+    // tile maxima for the coarse terrain test ahead of the prism walk (terrain_max_under)
+    const int mrow = (model->hfield_nrow + HF_TILE - 1) / HF_TILE, mcol = (model->hfield_ncol + HF_TILE - 1) / HF_TILE;
+    std::vector<float> mip((size_t)mrow * mcol, 0.f);
+    for (int r = 0; r < model->hfield_nrow; r++)
+      for (int c = 0; c < model->hfield_ncol; c++) {
+        float& m = mip[(size_t)(r / HF_TILE) * mcol + c / HF_TILE];
+        const float h = hfield[(size_t)r * model->hfield_ncol + c];
+        m = ((r % HF_TILE) == 0 && (c % HF_TILE) == 0) ? h : (h > m ? h : m);
+      }
+    HIP_TRY(hipMalloc(&e->d_hfield_mip, mip.size() * sizeof(float)));
+    HIP_TRY(hipMemcpy(e->d_hfield_mip, mip.data(), mip.size() * sizeof(float), hipMemcpyHostToDevice));
   }
   default_params(e);
   { int rc2 = set_ranges(e, 1); if (rc2) return rc2; }   // (allocates the pacing events of the single-launch path)
@@ -706,7 +718,7 @@ int cosim_destroy(cosim_engine_t* e) {
   hipSetDevice(e->device);
   hipFree(e->d_model); hipFree(e->d_obs); hipFree(e->d_state); hipFree(e->d_params); hipFree(e->d_dbg);
   hipFree(e->d_hull_vert); hipFree(e->d_hull_adr); hipFree(e->d_hull_nbr); hipFree(e->d_hfield);
-  hipFree(e->d_hull_cell); hipFree(e->d_hull_cand);
+  hipFree(e->d_hull_cell); hipFree(e->d_hull_cand); hipFree(e->d_hfield_mip);
   hipFree(e->d_pairs); hipFree(e->d_gext); hipFree(e->d_ovf); hipFree(e->d_xcon); hipFree(e->d_xcnt); hipFree(e->d_xstate);
   for (hipEvent_t x : e->ev) hipEventDestroy(x);
   for (hipStream_t x : e->rstream) hipStreamDestroy(x);
@@ -809,6 +821,7 @@ int cosim_set_param(cosim_engine_t* e, const char* name, const float* host, int 
     }
     return COSIM_OK;
   }
+  else if (n == "block_cull") { e->block_cull = (int)host[0] != 0; return COSIM_OK; }   // narrowphase kernel's block tests (default 1); 0 for A/B runs and tests
   else if (n == "boxbox_mode") { e->pair_boxbox = (int)host[0] != 0; return COSIM_OK; }   // 1: box-box pairs through mjc_BoxBox (default), 0: through MPR
   else if (n == "pair_mode") { e->pair_coop = (int)host[0] != 0; return COSIM_OK; }   // 1: hull pairs one at a time, wave-cooperative scans
   else if (n == "envs_per_wave") {   // 2: the two-environments-per-wave kernel (flat flamingo_light_v1, even env counts); 1: one per wave
@@ -842,10 +855,10 @@ static KArgs base_args(cosim_engine* e) {
   memset(&a, 0, sizeof a);
   a.dm = e->d_model; a.ob = e->d_obs; a.lay = e->lay; a.state = e->d_state; a.params = e->d_params;
   a.hull_vert = e->d_hull_vert; a.hull_adr = e->d_hull_adr; a.hull_nbr = e->d_hull_nbr; a.hfield = e->d_hfield;
-  a.hull_cell = e->d_hull_cell; a.hull_cand = e->d_hull_cand;
+  a.hull_cell = e->d_hull_cell; a.hull_cand = e->d_hull_cand; a.hfield_mip = e->d_hfield_mip;
   a.pairs = e->d_pairs; a.gext = e->d_gext;
   a.n_envs = e->n_envs; a.seed_lo = (unsigned)e->seed; a.seed_hi = (unsigned)(e->seed >> 32); a.env_id0 = e->env_id0;
-  a.tol32 = e->tol32; a.ls_scale = e->ls_scale; a.max_newton = e->max_newton; a.max_ls = e->max_ls; a.nsub_override = e->nsub_override; a.pair_coop = e->pair_coop; a.pair_boxbox = e->pair_boxbox;
+  a.tol32 = e->tol32; a.ls_scale = e->ls_scale; a.max_newton = e->max_newton; a.max_ls = e->max_ls; a.nsub_override = e->nsub_override; a.pair_coop = e->pair_coop; a.pair_boxbox = e->pair_boxbox; a.block_cull = e->block_cull;
   for (int k = 0; k < 4; k++) a.prio[k] = e->prio[k];
   a.ovf = nullptr; a.roll_steps = 1;
   a.xcon = e->d_xcon; a.xcnt = e->d_xcnt; a.xstate = e->d_xstate; a.nw = e->narrow_waves; a.sub_index = 0; a.sub_total = 0;

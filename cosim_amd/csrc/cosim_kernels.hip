@@ -47,6 +47,7 @@ struct KArgs {
   const int2* hull_cell;     // support maps (cosim_hullmap.h): (start, count) per cell, candidates (x, y, z, vertex index)
   const float4* hull_cand;
   const float* hfield;
+  const float* hfield_mip;   // highest vertex of each tile of HF_TILE x HF_TILE vertices (row-major, ceil(nrow / HF_TILE) x ceil(ncol / HF_TILE))
   const unsigned* pairs;  // robot-robot candidate pairs: geom1 | geom2 << 16
   const float4* gext;     // per geom: MPR centre (body frame) xyz, raw sliding friction w
   const float* actions;   // [N, nu]
@@ -67,6 +68,7 @@ struct KArgs {
   int max_newton, max_ls;
   int nsub_override;      // > 0: physics substeps per control step (diagnostics; 0 = the model's frame_skip)
   int pair_coop;          // robot-robot pairs with a hull: 1 = one at a time, wave-cooperative vertex scans; 0 = lane-parallel
+  int block_cull;         // narrowphase kernel: 1 = blocks of 8 prisms are tested before their prisms; 0 = every block goes on to the per-prism pass
   int pair_boxbox;        // box-box pairs: 1 = mjc_BoxBox (up to eight contacts), 0 = through MPR like the other convex pairs (one contact)
   int prio[4];            // wave priority by solver lag: expected Newton iterations per substep, then the three lag thresholds
   // split pipeline (heightfield narrowphase in a kernel of its own, see env_narrow_kernel): one launch = one substep
@@ -289,6 +291,11 @@ struct CtLds {
   // rotation (row-major, local -> world)[9], half extents[3]
   float hf_box[(HF && SLIM) ? 24 : 1][16];
   float hf_org[(HF && SLIM) ? 24 : 1][2];   // local (x, y) of the sub-grid's first vertex (column cmin, row rmin)
+  // narrowphase kernel, two-level walk: a block is up to 8 consecutive prisms of one strip row (4 cells); per geom the end of its
+  // blocks in the flattened block list; blocks that passed the block tests, in order, waiting for the per-prism pass
+  static constexpr int HBB = 2;   // sub-batches of 64 blocks per block pass
+  int hf_bend[(HF && SLIM) ? 24 : 1];
+  int hf_blist[(HF && SLIM) ? 8 * HFB + 64 * HBB : 1];
 };
 template <bool HF, int NB, int MC, int MCP, bool SLIM>
 struct CtLds<false, HF, NB, MC, MCP, SLIM> {};
@@ -515,24 +522,45 @@ __device__ __forceinline__ int prim_plane_contacts(const REC& R, const float* xq
   return cnt;
 }
 
+constexpr int HF_TILE = 8;
 struct Terrain {  // heightfield geometry; (ox, oy) = world position of the local frame origin (the base's x, y)
   const float* data;
+  const float* mip;   // per tile of HF_TILE x HF_TILE vertices: the highest one
   int nrow, ncol;
   float sx, sy, sz, gz;
   double ox, oy, dx, dy;   // ox, oy already relative to the hfield centre: local x -> field x = x + ox
 };
-// highest terrain vertex under a bounding sphere's footprint (world z); -inf when the sphere is off the field.  Conservative
-// pre-test ahead of the prism walk: a geom whose lowest point is above it cannot touch any prism below it.
+// highest terrain vertex of the tiles under a bounding sphere's footprint (world z); -inf when the sphere is off the field.
+// Conservative pre-test ahead of the prism walk: a geom whose lowest point is above it cannot touch any prism below it.  Reads the
+// vertices themselves when the window is at most 4 x 4 (coarse terrain), else the tile maxima (at most 6 x 6 tiles = a footprint of
+// 40 cells across, a row of tiles per trip): a 13 x 13 window of vertices read one dependent load at a time cost every wave of the
+// narrowphase kernel 64 k cycles per substep.
 __device__ __forceinline__ float terrain_max_under(const Terrain& T, const float* ctr, float rb) {
   const double lx = (double)ctr[0] + T.ox, ly = (double)ctr[1] + T.oy;
   if (fabs(lx) - rb > T.sx || fabs(ly) - rb > T.sy) return -3.0e38f;
   int cmin = (int)floor((lx - rb + T.sx) / T.dx), cmax = (int)ceil((lx + rb + T.sx) / T.dx);
   int rmin = (int)floor((ly - rb + T.sy) / T.dy), rmax = (int)ceil((ly + rb + T.sy) / T.dy);
   cmin = max(cmin, 0); rmin = max(rmin, 0); cmax = min(cmax, T.ncol - 1); rmax = min(rmax, T.nrow - 1);
-  cmax = min(cmax, cmin + 12); rmax = min(rmax, rmin + 12);
+  if (cmax - cmin < 4 && rmax - rmin < 4) {   // coarse terrain (cells of decimetres): the window's own vertices, all loads in flight
+    float v[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) v[k] = T.data[min(rmin + (k >> 2), rmax) * T.ncol + min(cmin + (k & 3), cmax)];
+    float hmax = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; k++) hmax = fmaxf(hmax, v[k]);
+    return T.gz + T.sz * hmax;
+  }
+  const int mcol = (T.ncol + HF_TILE - 1) / HF_TILE;
+  const int c0 = cmin / HF_TILE, c1 = cmax / HF_TILE, r0 = rmin / HF_TILE, r1 = rmax / HF_TILE;
+  if (c1 - c0 > 5 || r1 - r0 > 5) return 3.0e38f;   // (the caller's size limit keeps footprints within 6 tiles; wider: no verdict)
   float hmax = 0.f;
-  for (int r = rmin; r <= rmax; r++)
-    for (int c = cmin; c <= cmax; c++) hmax = fmaxf(hmax, T.data[r * T.ncol + c]);
+  for (int r = r0; r <= r1; r++) {
+    float v[6];
+#pragma unroll
+    for (int k = 0; k < 6; k++) v[k] = T.mip[r * mcol + min(c0 + k, c1)];
+#pragma unroll
+    for (int k = 0; k < 6; k++) hmax = fmaxf(hmax, v[k]);
+  }
   return T.gz + T.sz * hmax;
 }
 // terrain elevation under (x, y) on the ray triangulation (mj_rayHfield: cell split along (r,c)-(r+1,c+1)); inside = on the field
@@ -1064,7 +1092,7 @@ __device__ __forceinline__ void env_body(KArgsP kargs_p, const int env, typename
         const auto& R = dm.rec[ln];
         constexpr bool is_plane = !HF;
         Terrain T;
-        T.data = hfdata_; T.nrow = dm.hfield_nrow; T.ncol = dm.hfield_ncol;
+        T.data = hfdata_; T.mip = A.hfield_mip; T.nrow = dm.hfield_nrow; T.ncol = dm.hfield_ncol;
         T.sx = dm.hfield_size[0]; T.sy = dm.hfield_size[1]; T.sz = dm.hfield_size[2]; T.gz = dm.ground_pos[2];
         T.ox = (double)S.qpos[0] - (double)dm.ground_pos[0]; T.oy = (double)S.qpos[1] - (double)dm.ground_pos[1];
         T.dx = is_plane ? 1.0 : 2.0 * (double)T.sx / (double)(T.ncol - 1); T.dy = is_plane ? 1.0 : 2.0 * (double)T.sy / (double)(T.nrow - 1);
@@ -1174,9 +1202,9 @@ __device__ __forceinline__ void env_body(KArgsP kargs_p, const int env, typename
                   lo[k] = ctr[k] - e; hi[k] = ctr[k] + e;
                 }
               }
-              // coarse terrain: the highest vertex under the bounding sphere's footprint (a 12 x 12 window at most) against the box's
-              // lowest point
-              if (!out && 2.0 * rb <= 11.0 * T.dx && 2.0 * rb <= 11.0 * T.dy) out = lo[2] - margin > terrain_max_under(T, ctr, rb);
+              // coarse terrain: the highest vertex of the 8 x 8-vertex tiles under the bounding sphere's footprint (6 x 6 tiles at
+              // most) against the box's lowest point
+              if (!out && 2.0 * rb <= 40.0 * T.dx && 2.0 * rb <= 40.0 * T.dy) out = lo[2] - margin > terrain_max_under(T, ctr, rb);
               if (!out) {
                 if (gt != CS_GEOM_MESH) {
 #pragma unroll
@@ -1250,6 +1278,16 @@ __device__ __forceinline__ void env_body(KArgsP kargs_p, const int env, typename
             for (int o = 1; o < 32; o <<= 1) { const int t = __shfl_up(end, o, 64); if (ln >= o) end += t; }
             if (ln < 24) { S.hf_end[ln] = end; S.hf_cnt[ln] = 0; }
             const int total = __builtin_amdgcn_readlane(end, 23);   // lanes past ngeom add nothing
+            int btotal = 0;
+            if constexpr (KM == 1) {
+              // blocks of up to 8 consecutive prisms of a strip row: rows x ceil(ppr / 8) per geom, same (geom, strip) order
+              int bend = 0;
+              if (n_items > 0) { const int ppr_ = S.hf_ppr[ln]; bend = small_div(n_items, ppr_) * ((ppr_ + 7) >> 3); }
+#pragma unroll
+              for (int o = 1; o < 32; o <<= 1) { const int t = __shfl_up(bend, o, 64); if (ln >= o) bend += t; }
+              if (ln < 24) S.hf_bend[ln] = bend;
+              btotal = __builtin_amdgcn_readlane(bend, 23);
+            }
             WSYNC();
             PEXT_ADD(0);
 
@@ -1339,10 +1377,13 @@ __device__ __forceinline__ void env_body(KArgsP kargs_p, const int env, typename
             //   probe pass (zlist): MPR's first two exits decide most survivors; the undecided ones -> list;
             //   full pass (list): MPR, ordered append of the hits.
             // The later stage runs as soon as its list holds a full batch; the tails are drained at the end.
-            int nlist = 0, nz = 0, base = 0;
-            bool walked = total == 0;
-            while (!(walked && nz == 0 && nlist == 0)) {
-              if (nlist >= 64 || (walked && nz == 0)) {
+            // The narrowphase kernel (fine terrain under a big robot: ~15 000 prisms under an env's geoms per substep, one in twenty of
+            // them near a geom) walks in two levels: a block pass over blocks of 8 prisms -- one height test and one oriented-box test
+            // for the block, from its 10 vertices -- and the per-prism height pass only for the prisms of blocks that passed.
+            int nlist = 0, nz = 0, base = 0, nb = 0;
+            bool walked = KM == 1 ? btotal == 0 : total == 0;
+            while (!(walked && nb == 0 && nz == 0 && nlist == 0)) {
+              if (nlist >= 64 || (walked && nb == 0 && nz == 0)) {
                 const int cnt = min(nlist, 64);
                 if (PROF) { pext[6] += 1; }
                 run_listed(cnt);
@@ -1352,7 +1393,7 @@ __device__ __forceinline__ void env_body(KArgsP kargs_p, const int env, typename
                 nlist -= cnt;
                 WSYNC();
                 PEXT_ADD(2);
-              } else if (nz >= 64 || walked) {
+              } else if (nz >= 64 || (walked && nb == 0)) {
                 const int cnt = min(nz, 64);
                 bool maybe = false;
                 int item = 0;
@@ -1384,6 +1425,189 @@ __device__ __forceinline__ void env_body(KArgsP kargs_p, const int env, typename
                 WSYNC();
                 PEXT_ADD(1);
                 if (PROF) { pext[4] += 1; }
+              } else if (KM == 1 && (nb >= 8 * L::HFB || walked)) {
+                if constexpr (KM == 1) {
+                  // per-prism pass over the prisms of up to 8 x HB listed blocks (8 lanes per block): the height test of
+                  // mjc_ConvexHField and the oriented-box test, per prism; survivors -> zlist, in (geom, strip) order
+                  constexpr int HB = L::HFB;
+                  const int nbk = min(nb, 8 * HB);
+                  bool alive[HB];
+                  float hv[HB][3], lo2[HB], add[HB], cxy[HB][2];
+                  int gsel[HB], itm[HB];
+#pragma unroll
+                  for (int j = 0; j < HB; j++) {
+                    const int slot = (ln >> 3) + 8 * j, sub = ln & 7;
+                    alive[j] = false;
+                    lo2[j] = 0.f; add[j] = 0.f; cxy[j][0] = cxy[j][1] = 0.f; gsel[j] = 0; itm[j] = 0;
+                    int idx[3] = {0, 0, 0};
+                    if (slot < nbk) {
+                      const int bi = S.hf_blist[slot];
+                      int g = 0;
+                      while (bi >= S.hf_bend[g]) g++;
+                      const int kb = bi - (g > 0 ? S.hf_bend[g > 0 ? g - 1 : 0] : 0), ppr = S.hf_ppr[g], bpr = (ppr + 7) >> 3;
+                      const int rrow = small_div(kb, bpr), kk = ((kb - rrow * bpr) << 3) + sub;
+                      if (kk < ppr) {
+                        const int r = S.hf_rmin[g] + rrow, cmin = S.hf_cmin[g];
+                        itm[j] = (g > 0 ? S.hf_end[g > 0 ? g - 1 : 0] : 0) + rrow * ppr + kk;
+                        lo2[j] = S.hf_lo[g]; add[j] = T.gz + S.hf_mg[g];
+                        int csum = 0, rsum = 0;
+#pragma unroll
+                        for (int i = 0; i < 3; i++) {
+                          const int v = kk + i, c = cmin + (v >> 1), rr = r + 1 - (v & 1);
+                          idx[i] = rr * T.ncol + c;
+                          csum += c; rsum += rr;
+                        }
+                        // centroid of the footprint, relative to the sub-grid's first vertex (fp32 is ample: the box is grown by 0.7 cell
+                        // diagonals where 0.67 would do, and a sub-grid is at most a few metres wide)
+                        gsel[j] = g;
+                        cxy[j][0] = S.hf_org[g][0] + (float)(csum - 3 * cmin) * (1.f / 3.f) * (float)T.dx;
+                        cxy[j][1] = S.hf_org[g][1] + (float)(rsum - 3 * S.hf_rmin[g]) * (1.f / 3.f) * (float)T.dy;
+                        alive[j] = S.hf_cnt[g] < 50;
+                      }
+                    }
+                    if (8 * j < nbk) {
+#pragma unroll
+                      for (int i = 0; i < 3; i++) hv[j][i] = T.data[idx[i]];
+                    } else {
+#pragma unroll
+                      for (int i = 0; i < 3; i++) hv[j][i] = 0.f;
+                    }
+                  }
+                  int moved[2];   // blocks left over: < 8 x HB + 64 x HBB, the first 8 x HB of them just consumed
+#pragma unroll
+                  for (int q = 0; q < 2; q++) moved[q] = (nbk + ln + 64 * q < nb) ? S.hf_blist[nbk + ln + 64 * q] : 0;
+#pragma unroll
+                  for (int j = 0; j < HB; j++) {
+                    if (!(8 * j < nbk)) break;
+                    bool below = true;
+#pragma unroll
+                    for (int i = 0; i < 3; i++) below = below && (hv[j][i] * T.sz + add[j] < lo2[j]);
+                    // A prism that touches the geom holds a point p of the geom's box whose (x, y) lies in the prism's footprint, i.e.
+                    // within `grow` of the footprint's centroid c: (c.x, c.y, p.z) then lies in the GROWN box, so the vertical line
+                    // through c meets the grown box, and no lower than it enters it can p be.  Line misses the box, or enters it above
+                    // the prism's (margin-raised) top: the prism cannot touch.  This is what thins out the walk of a long limb lying
+                    // askew (its footprint is a sliver of its axis-aligned sub-grid) or tilted (one end high above the steps).
+                    if (alive[j] && !below) {
+                      const float* B = S.hf_box[gsel[j]];
+                      const float rx = cxy[j][0] - B[0], ry = cxy[j][1] - B[1], rz = -B[2];   // line origin (c.x, c.y, 0) relative to the box centre
+                      float t0 = -3.0e38f, t1 = 3.0e38f;
+                      bool miss = false;
+#pragma unroll
+                      for (int k = 0; k < 3; k++) {
+                        const float o_ = B[3 + k] * rx + B[6 + k] * ry + B[9 + k] * rz;   // R^T (origin - centre), component k
+                        const float d_ = B[9 + k];                                           // R^T e_z, component k
+                        const float hk = B[12 + k];
+                        if (fabsf(d_) < 1e-6f) miss = miss || fabsf(o_) > hk;
+                        else {
+                          const float inv = 1.f / d_, ta = (-hk - o_) * inv, tb = (hk - o_) * inv;
+                          t0 = fmaxf(t0, fminf(ta, tb)); t1 = fminf(t1, fmaxf(ta, tb));
+                        }
+                      }
+                      const float ztop = fmaxf(hv[j][0], fmaxf(hv[j][1], hv[j][2])) * T.sz + add[j];
+                      if (miss || t0 > t1 || t0 > ztop + 1e-5f) below = true;
+                    }
+                    const bool al = alive[j] && !below;
+                    const unsigned long long am = __ballot(al);
+                    if (al) S.hf_zlist[nz + __popcll(am & lanemask_lt(ln))] = itm[j];
+                    nz += __popcll(am);
+                  }
+                  WSYNC();
+#pragma unroll
+                  for (int q = 0; q < 2; q++) if (nbk + ln + 64 * q < nb) S.hf_blist[ln + 64 * q] = moved[q];
+                  nb -= nbk;
+                  WSYNC();
+                  PEXT_ADD(0);
+                }
+              } else if (KM == 1) {
+                if constexpr (KM == 1) {
+                  // block pass: HBB sub-batches of 64 blocks, their vertex heights (10 per block: 5 columns of two rows) in flight together
+                  constexpr int HBB = L::HBB;
+                  int g0 = 0;
+                  while (base >= __builtin_amdgcn_readfirstlane(S.hf_bend[g0])) g0++;   // uniform; terminates: base < btotal = hf_bend[23]
+                  if (__builtin_amdgcn_readfirstlane(S.hf_cnt[g0]) >= 50) {   // this geom has its 50 contacts: skip the rest of its blocks
+                    base = __builtin_amdgcn_readfirstlane(S.hf_bend[g0]);
+                  } else {
+                    const float cell_reach = 0.7f * sqrtf((float)(T.dx * T.dx + T.dy * T.dy));   // what hf_box is grown by already
+                    bool alive[HBB];
+                    float hmax[HBB], lo2[HBB], add[HBB], cxy[HBB][2], extra[HBB];
+                    int gsel[HBB];
+#pragma unroll
+                    for (int j = 0; j < HBB; j++) {
+                      const int bi = base + ln + 64 * j;
+                      alive[j] = false;
+                      hmax[j] = 0.f; lo2[j] = 0.f; add[j] = 0.f; cxy[j][0] = cxy[j][1] = 0.f; extra[j] = 0.f; gsel[j] = 0;
+                      int idx[10];
+#pragma unroll
+                      for (int i = 0; i < 10; i++) idx[i] = 0;
+                      int nvx = 0;
+                      if (bi < btotal) {
+                        int g = g0;
+                        while (bi >= S.hf_bend[g]) g++;
+                        const int kb = bi - (g > 0 ? S.hf_bend[g > 0 ? g - 1 : 0] : 0), ppr = S.hf_ppr[g], bpr = (ppr + 7) >> 3;
+                        const int rrow = small_div(kb, bpr), kk0 = (kb - rrow * bpr) << 3, nk = min(8, ppr - kk0);
+                        const int r = S.hf_rmin[g] + rrow, cmin = S.hf_cmin[g];
+                        nvx = nk + 2;   // strip vertices kk0 .. kk0 + nk + 1 carry the block's prisms
+#pragma unroll
+                        for (int i = 0; i < 10; i++) {
+                          const int v = kk0 + min(i, nvx - 1), c = cmin + (v >> 1), rr = r + 1 - (v & 1);
+                          idx[i] = rr * T.ncol + c;
+                        }
+                        lo2[j] = S.hf_lo[g]; add[j] = T.gz + S.hf_mg[g];
+                        gsel[j] = g;
+                        // centre of the block's footprint (columns kk0 / 2 .. (kk0 + nk + 1) / 2 of the sub-grid, one row of cells) and how
+                        // far a point of the footprint lies from it at most, beyond what the box is grown by already
+                        const int ca = kk0 >> 1, cb = (kk0 + nk + 1) >> 1;
+                        const float hx = 0.5f * (float)(cb - ca) * (float)T.dx, hy = 0.5f * (float)T.dy;
+                        cxy[j][0] = S.hf_org[g][0] + 0.5f * (float)(ca + cb) * (float)T.dx;
+                        cxy[j][1] = S.hf_org[g][1] + ((float)rrow + 0.5f) * (float)T.dy;
+                        extra[j] = fmaxf(sqrtf(hx * hx + hy * hy) * 1.0001f - cell_reach, 0.f);
+                        alive[j] = S.hf_cnt[g] < 50;
+                      }
+                      if (j == 0 || __builtin_amdgcn_readfirstlane(base) + 64 * j < __builtin_amdgcn_readfirstlane(btotal)) {
+                        float m_ = -3.0e38f;
+#pragma unroll
+                        for (int i = 0; i < 10; i++) m_ = fmaxf(m_, T.data[idx[i]]);
+                        hmax[j] = m_;
+                      }
+                    }
+#pragma unroll
+                    for (int j = 0; j < HBB; j++) {
+                      if (j > 0 && !(__builtin_amdgcn_readfirstlane(base) + 64 * j < __builtin_amdgcn_readfirstlane(btotal))) break;
+                      // every prism of the block lies below the geom's lowest point <=> the block's highest vertex does
+                      const float ztop = hmax[j] * T.sz + add[j];
+                      bool below = ztop < lo2[j] && A.block_cull != 0;
+                      // the oriented-box test of the per-prism pass for the whole block: a prism of the block that touches the geom
+                      // holds a point of the geom's box over the block's footprint, within `reach` of its centre c; the vertical line
+                      // through c then meets the box grown by that reach, no higher than the block's highest (margin-raised) vertex
+                      if (alive[j] && !below && A.block_cull != 0) {
+                        const float* B = S.hf_box[gsel[j]];
+                        const float rx = cxy[j][0] - B[0], ry = cxy[j][1] - B[1], rz = -B[2];
+                        float t0 = -3.0e38f, t1 = 3.0e38f;
+                        bool miss = false;
+#pragma unroll
+                        for (int k = 0; k < 3; k++) {
+                          const float o_ = B[3 + k] * rx + B[6 + k] * ry + B[9 + k] * rz;
+                          const float d_ = B[9 + k];
+                          const float hk = B[12 + k] + extra[j];
+                          if (fabsf(d_) < 1e-6f) miss = miss || fabsf(o_) > hk;
+                          else {
+                            const float inv = 1.f / d_, ta = (-hk - o_) * inv, tb = (hk - o_) * inv;
+                            t0 = fmaxf(t0, fminf(ta, tb)); t1 = fminf(t1, fmaxf(ta, tb));
+                          }
+                        }
+                        if (miss || t0 > t1 || t0 > ztop + 1e-5f) below = true;
+                      }
+                      const bool al = alive[j] && !below;
+                      const unsigned long long am = __ballot(al);
+                      if (al) S.hf_blist[nb + __popcll(am & lanemask_lt(ln))] = base + ln + 64 * j;
+                      nb += __popcll(am);
+                    }
+                    base += 64 * HBB;
+                    WSYNC();
+                  }
+                  walked = base >= btotal;
+                  PEXT_ADD(0);
+                }
               } else {
                 int g0 = 0;
                 while (base >= __builtin_amdgcn_readfirstlane(S.hf_end[g0])) g0++;   // uniform; terminates: base < total = hf_end[23]
@@ -1395,13 +1619,11 @@ __device__ __forceinline__ void env_body(KArgsP kargs_p, const int env, typename
                   constexpr int HB = L::HFB;
                   bool alive[HB];
                   float hv[HB][3], lo2[HB], add[HB];
-                  float cxy[HB][2];   // narrowphase kernel: centroid of the prism's footprint
-                  int gsel[HB];
 #pragma unroll
                   for (int j = 0; j < HB; j++) {
                     const int item = base + ln + 64 * j;
                     alive[j] = false;
-                    lo2[j] = 0.f; add[j] = 0.f; cxy[j][0] = cxy[j][1] = 0.f; gsel[j] = 0;
+                    lo2[j] = 0.f; add[j] = 0.f;
                     int idx[3] = {0, 0, 0};
                     if (item < total) {
                       int g = g0;
@@ -1409,19 +1631,10 @@ __device__ __forceinline__ void env_body(KArgsP kargs_p, const int env, typename
                       const int k = item - (g > 0 ? S.hf_end[g > 0 ? g - 1 : 0] : 0), ppr = S.hf_ppr[g], rrow = small_div(k, ppr), kk = k - rrow * ppr;
                       const int r = S.hf_rmin[g] + rrow, cmin = S.hf_cmin[g];
                       lo2[j] = S.hf_lo[g]; add[j] = T.gz + S.hf_mg[g];
-                      int csum = 0, rsum = 0;
 #pragma unroll
                       for (int i = 0; i < 3; i++) {
                         const int v = kk + i, c = cmin + (v >> 1), rr = r + 1 - (v & 1);
                         idx[i] = rr * T.ncol + c;
-                        csum += c; rsum += rr;
-                      }
-                      if constexpr (KM == 1) {
-                        // centroid of the footprint, relative to the sub-grid's first vertex (fp32 is ample: the box is grown by 0.7 cell
-                        // diagonals where 0.67 would do, and a sub-grid is at most a few metres wide)
-                        gsel[j] = g;
-                        cxy[j][0] = S.hf_org[g][0] + (float)(csum - 3 * cmin) * (1.f / 3.f) * (float)T.dx;
-                        cxy[j][1] = S.hf_org[g][1] + (float)(rsum - 3 * S.hf_rmin[g]) * (1.f / 3.f) * (float)T.dy;
                       }
                       alive[j] = S.hf_cnt[g] < 50;
                     }
@@ -1440,32 +1653,6 @@ __device__ __forceinline__ void env_body(KArgsP kargs_p, const int env, typename
                     bool below = true;
 #pragma unroll
                     for (int i = 0; i < 3; i++) below = below && (hv[j][i] * T.sz + add[j] < lo2[j]);
-                    if constexpr (KM == 1) {
-                      // A prism that touches the geom holds a point p of the geom's box whose (x, y) lies in the prism's footprint, i.e.
-                      // within `grow` of the footprint's centroid c: (c.x, c.y, p.z) then lies in the GROWN box, so the vertical line
-                      // through c meets the grown box, and no lower than it enters it can p be.  Line misses the box, or enters it above
-                      // the prism's (margin-raised) top: the prism cannot touch.  This is what thins out the walk of a long limb lying
-                      // askew (its footprint is a sliver of its axis-aligned sub-grid) or tilted (one end high above the steps).
-                      if (alive[j] && !below) {
-                        const float* B = S.hf_box[gsel[j]];
-                        const float rx = cxy[j][0] - B[0], ry = cxy[j][1] - B[1], rz = -B[2];   // line origin (c.x, c.y, 0) relative to the box centre
-                        float t0 = -3.0e38f, t1 = 3.0e38f;
-                        bool miss = false;
-#pragma unroll
-                        for (int k = 0; k < 3; k++) {
-                          const float o_ = B[3 + k] * rx + B[6 + k] * ry + B[9 + k] * rz;   // R^T (origin - centre), component k
-                          const float d_ = B[9 + k];                                           // R^T e_z, component k
-                          const float hk = B[12 + k];
-                          if (fabsf(d_) < 1e-6f) miss = miss || fabsf(o_) > hk;
-                          else {
-                            const float inv = 1.f / d_, ta = (-hk - o_) * inv, tb = (hk - o_) * inv;
-                            t0 = fmaxf(t0, fminf(ta, tb)); t1 = fminf(t1, fmaxf(ta, tb));
-                          }
-                        }
-                        const float ztop = fmaxf(hv[j][0], fmaxf(hv[j][1], hv[j][2])) * T.sz + add[j];
-                        if (miss || t0 > t1 || t0 > ztop + 1e-5f) below = true;
-                      }
-                    }
                     const bool al = alive[j] && !below;
                     const unsigned long long am = __ballot(al);
                     if (al) S.hf_zlist[nz + __popcll(am & lanemask_lt(ln))] = base + ln + 64 * j;
@@ -2736,7 +2923,7 @@ __device__ __forceinline__ void env_body(KArgsP kargs_p, const int env, typename
           const float wy = (2.f * qx * qy + 2.f * qz * qw) * xr + (1.f - 2.f * qx * qx - 2.f * qz * qz) * yr;
           const float wz = S.qpos[2] + (2.f * qx * qz - 2.f * qy * qw) * xr + (2.f * qy * qz + 2.f * qx * qw) * yr;
           Terrain T;
-          T.data = A.hfield; T.nrow = dm.hfield_nrow; T.ncol = dm.hfield_ncol;
+          T.data = A.hfield; T.mip = A.hfield_mip; T.nrow = dm.hfield_nrow; T.ncol = dm.hfield_ncol;
           T.sx = dm.hfield_size[0]; T.sy = dm.hfield_size[1]; T.sz = dm.hfield_size[2]; T.gz = dm.ground_pos[2];
           T.ox = (double)S.qpos[0] - (double)dm.ground_pos[0]; T.oy = (double)S.qpos[1] - (double)dm.ground_pos[1];
           T.dx = 2.0 * (double)T.sx / (double)(T.ncol - 1); T.dy = 2.0 * (double)T.sy / (double)(T.nrow - 1);

@@ -94,7 +94,9 @@ int cosim_query(const cosim_engine_t* e, const char* name);
  * to the fused kernel), "fixup" (0 switches the
  * large-capacity fix-up launches off: contacts beyond the fleet kernel's slots are then left out and counted), "support_map" (1,
  * default: support queries on mesh geoms with 32 or more hull vertices go through the hull's support map -- the few vertices that can
- * win in the direction's cube-map cell, same arg max as the scan; 0: every query scans the whole hull, for A/B runs and tests).
+ * win in the direction's cube-map cell, same arg max as the scan; 0: every query scans the whole hull, for A/B runs and tests),
+ * "block_cull" (1, default: the narrowphase kernel of the split pipeline tests blocks of 8 prisms -- height and oriented box -- before
+ * their prisms; 0: every block goes on to the per-prism tests; same contacts either way).
  * cosim_query additionally answers "contact_slots" / "pair_slots" (capacity of the selected kernel variant: heightfields with cells
  * of 10 cm or more select the 48-slot variants of flamingo_light_v1 / w4_p_v2), "fixup_contact_slots" (capacity of the kernel that
  * redoes a control step whose contacts did not fit; 0: this model / terrain has none), "ranges" and "lds_bytes". */

@@ -596,3 +596,31 @@ def test_device_support_routines_agree_map_scan_lane_parallel_and_cooperative(ro
         checked += 1
     assert checked >= 2
     env.close()
+
+
+def test_block_tests_of_the_prism_walk_remove_only_prisms_that_cannot_touch():
+    """The narrowphase kernel (humanoid on 1 cm stairs) tests blocks of 8 prisms before their prisms.  A block is dropped only if none
+    of its prisms can touch the geom, so the contacts -- and with them every bit of the fleet -- are those of the walk that sends every
+    block on to the per-prism tests."""
+    import torch
+    from cosim_amd.batched_env import BatchedEnv
+    from cosim_amd.config import make_config
+    n, K = 192, 80
+    cfg = make_config("humanoid_p_v0", terrain="stairs_up_hard", num_envs=n, seed=12)
+    outs = []
+    for cull in (1.0, 0.0):
+        env = BatchedEnv(cfg, num_envs=n, seed=12, auto_reset=True, gain_noise=0.1)
+        assert env.engine.query("split") > 0
+        env.engine.set_param("block_cull", np.array([cull], dtype=np.float32))
+        acts = (0.6 * torch.randn((K, n, env.action_dim), device="cuda:0", generator=torch.Generator(device="cuda:0").manual_seed(3))).clamp_(-1, 1)
+        env.reset()
+        states = []
+        for k in range(K):
+            s, _, _, _ = env.step(acts[k])
+            states.append(s.clone())
+        d = env.get_data()
+        st = env.solver_stats()
+        outs.append((torch.stack(states), d.qpos.clone(), st["rows"], st["max_contacts"]))
+        env.close()
+    assert outs[0][2] == outs[1][2] and outs[0][3] == outs[1][3] and outs[0][3] > 60      # fallen humanoids on the steps: many contacts
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
