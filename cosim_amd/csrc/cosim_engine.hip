@@ -54,6 +54,7 @@ struct cosim_engine {
   int nsub_override = 0;
   int pair_coop = 1;
   int block_cull = 1;
+  int coop_walk = 0;
   int pair_boxbox = 1;
   int prio[4] = {3, 0, 2, 4};   // wave priority by solver lag (see the kernel): usual iterations per substep, lag thresholds
   // timing
@@ -80,7 +81,7 @@ struct cosim_engine {
   void (*launch_narrow)(cosim_engine*, const KArgs&, int grid, hipStream_t) = nullptr;
   void (*launch_stepx)(cosim_engine*, const KArgs&, int grid, hipStream_t) = nullptr;
   bool split = false;
-  int narrow_waves = 8;
+  int narrow_waves = 6;
   int narrow_occ = 2;   // narrowphase kernel variant: waves per SIMD its registers are allocated for (0: diagnostic build)
   float *d_xcon = nullptr, *d_xstate = nullptr;
   int* d_xcnt = nullptr;
@@ -821,6 +822,7 @@ int cosim_set_param(cosim_engine_t* e, const char* name, const float* host, int 
     }
     return COSIM_OK;
   }
+  else if (n == "coop_walk") { e->coop_walk = (int)host[0] != 0; return COSIM_OK; }   // 1: the round-2 cooperative walk of hulls with few prisms under them (A/B)
   else if (n == "block_cull") { e->block_cull = (int)host[0] != 0; return COSIM_OK; }   // narrowphase kernel's block tests (default 1); 0 for A/B runs and tests
   else if (n == "boxbox_mode") { e->pair_boxbox = (int)host[0] != 0; return COSIM_OK; }   // 1: box-box pairs through mjc_BoxBox (default), 0: through MPR
   else if (n == "pair_mode") { e->pair_coop = (int)host[0] != 0; return COSIM_OK; }   // 1: hull pairs one at a time, wave-cooperative scans
@@ -858,7 +860,7 @@ static KArgs base_args(cosim_engine* e) {
   a.hull_cell = e->d_hull_cell; a.hull_cand = e->d_hull_cand; a.hfield_mip = e->d_hfield_mip;
   a.pairs = e->d_pairs; a.gext = e->d_gext;
   a.n_envs = e->n_envs; a.seed_lo = (unsigned)e->seed; a.seed_hi = (unsigned)(e->seed >> 32); a.env_id0 = e->env_id0;
-  a.tol32 = e->tol32; a.ls_scale = e->ls_scale; a.max_newton = e->max_newton; a.max_ls = e->max_ls; a.nsub_override = e->nsub_override; a.pair_coop = e->pair_coop; a.pair_boxbox = e->pair_boxbox; a.block_cull = e->block_cull;
+  a.tol32 = e->tol32; a.ls_scale = e->ls_scale; a.max_newton = e->max_newton; a.max_ls = e->max_ls; a.nsub_override = e->nsub_override; a.pair_coop = e->pair_coop; a.pair_boxbox = e->pair_boxbox; a.block_cull = e->block_cull; a.coop_walk = e->coop_walk;
   for (int k = 0; k < 4; k++) a.prio[k] = e->prio[k];
   a.ovf = nullptr; a.roll_steps = 1;
   a.xcon = e->d_xcon; a.xcnt = e->d_xcnt; a.xstate = e->d_xstate; a.nw = e->narrow_waves; a.sub_index = 0; a.sub_total = 0;

@@ -68,6 +68,7 @@ struct KArgs {
   int max_newton, max_ls;
   int nsub_override;      // > 0: physics substeps per control step (diagnostics; 0 = the model's frame_skip)
   int pair_coop;          // robot-robot pairs with a hull: 1 = one at a time, wave-cooperative vertex scans; 0 = lane-parallel
+  int coop_walk;          // heightfield: 1 = hulls with few prisms under them are walked wave-cooperatively even when they have a support map (A/B)
   int block_cull;         // narrowphase kernel: 1 = blocks of 8 prisms are tested before their prisms; 0 = every block goes on to the per-prism pass
   int pair_boxbox;        // box-box pairs: 1 = mjc_BoxBox (up to eight contacts), 0 = through MPR like the other convex pairs (one contact)
   int prio[4];            // wave priority by solver lag: expected Newton iterations per substep, then the three lag thresholds
@@ -1250,9 +1251,11 @@ __device__ __forceinline__ void env_body(KArgsP kargs_p, const int env, typename
                       for (int k = 0; k < 3; k++) { S.hf_box[ln][k] = bc[k]; S.hf_box[ln][12 + k] = bh[k] + grow; }
                       for (int k = 0; k < 9; k++) S.hf_box[ln][3 + k] = bm[k];
                     }
-                    // a hull with only a few prisms under it (coarse terrain): its prisms one at a time with all 64 lanes sharing the
-                    // vertex scans -- 64 lanes each scanning a 700-vertex hull for a handful of items would cost more
-                    if (gt == CS_GEOM_MESH && n_items < 32 && R.g_hullnum > 64) { coop_geom = true; n_items = 0; }
+                    // a hull with only a few prisms under it (coarse terrain) and no support map: its prisms one at a time with all 64
+                    // lanes sharing the vertex scans -- 64 lanes each scanning a 700-vertex hull for a handful of items would cost
+                    // more.  With a support map a lane's query walks a handful of candidates: the prisms of all such hulls go through
+                    // the staged walk together, one MPR per lane, instead of one after the other.
+                    if (gt == CS_GEOM_MESH && n_items < 32 && R.g_hullnum > 64 && (dm.g_hullmap[ln] < 0 || A.coop_walk != 0)) { coop_geom = true; n_items = 0; }
                   }
                 }
               }

@@ -89,8 +89,8 @@ int cosim_query(const cosim_engine_t* e, const char* name);
  * twist space, 32 slots instead of the dense-row kernel's 14, at ~70 % of the speed; before the first step), "ls_tolerance_scale"
  * (multiplies the line-search tolerance; 1 = the model's), "ranges" (1..16: cosim_step issues the fleet as that many launches over
  * contiguous env ranges on engine-owned streams; default 1), "deferred_join" (see cosim_step / cosim_join), "inflight" (control steps cosim_step lets the host run ahead of each
- * range stream before it blocks, default 4, 0 = unbounded: deep queues step slower on this runtime), "split" (heightfield kernels that have the two-kernel pipeline -- humanoid_p_v0:
- * the prism walk in a kernel of its own, "narrow_waves" (default 4) waves per env, and the solver one substep per launch; 0 goes back
+ * range stream before it blocks, default 2, 0 = unbounded: deep queues step slower on this runtime), "split" (heightfield kernels that have the two-kernel pipeline -- humanoid_p_v0:
+ * the prism walk in a kernel of its own, "narrow_waves" (default 6) waves per env, and the solver one substep per launch; 0 goes back
  * to the fused kernel), "fixup" (0 switches the
  * large-capacity fix-up launches off: contacts beyond the fleet kernel's slots are then left out and counted), "support_map" (1,
  * default: support queries on mesh geoms with 32 or more hull vertices go through the hull's support map -- the few vertices that can

@@ -10,7 +10,7 @@ STEPS=${3:-40}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_${TAG}_${WL}
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-ARGS="$GRAFT_REPO_ROOT/bench.py --workload $WL --steps $STEPS --warmup 10 --no-cpu-baseline"
+ARGS="$GRAFT_REPO_ROOT/bench.py --workload $WL --steps $STEPS --warmup 10 --no-cpu-baseline --no-rollout"
 # 1. kernel trace + stats (per-kernel durations)
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ARGS > $OUT/trace.log 2>&1 || echo "trace pass failed"
 grep '^{' $OUT/trace.log | tail -n 1 > $OUT/bench_line.json
@@ -32,7 +32,7 @@ for f in glob.glob(out + "/trace/*/*kernel_trace.csv"):
     for r in csv.DictReader(open(f)):
         rows[r["Kernel_Name"]].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
 with open(out + "/kernel_trace_summary.txt", "w") as o:
-    o.write("rocprofv3 --kernel-trace --stats -- python3 bench.py --workload $WL --steps $STEPS --warmup 10 --no-cpu-baseline\n")
+    o.write("rocprofv3 --kernel-trace --stats -- python3 bench.py --workload $WL --steps $STEPS --warmup 10 --no-cpu-baseline --no-rollout\n")
     o.write(f"{'kernel':110s} {'calls':>6s} {'avg_us':>10s} {'min_us':>10s} {'max_us':>10s} {'total_ms':>10s}\n")
     for k, v in sorted(rows.items(), key=lambda kv: -sum(kv[1])):
         o.write(f"{k[:110]:110s} {len(v):6d} {sum(v)/len(v)/1e3:10.2f} {min(v)/1e3:10.2f} {max(v)/1e3:10.2f} {sum(v)/1e6:10.3f}\n")
