@@ -38,7 +38,7 @@ struct cosim_engine {
   DevObs* d_obs = nullptr;
   float *d_state = nullptr, *d_params = nullptr, *d_hull_vert = nullptr, *d_hfield = nullptr, *d_hfield_mip = nullptr, *d_dbg = nullptr;
   int *d_hull_adr = nullptr, *d_hull_nbr = nullptr;
-  int2* d_hull_cell = nullptr;      // support maps of the hulls (cosim_hullmap.h)
+  float4* d_hull_cell = nullptr;    // support maps of the hulls (cosim_hullmap.h)
   float4* d_hull_cand = nullptr;
   int hullmap_of_geom[64];          // what DevModel::g_hullmap holds while "support_map" is on
   unsigned* d_pairs = nullptr;   // robot-robot candidate pairs (geom1 | geom2 << 16)
@@ -625,8 +625,7 @@ int cosim_create(const cosim_model_t* model, const float* hull_vert, const int* 
   if (model->ngeom > e->geom_stage) { delete e; return fail(COSIM_EINVAL, "cosim_create: more collision geoms than the plane kernel stages contacts for"); }
   {
     // support maps of the mesh geoms' hulls (geoms that share a hull slice share the map)
-    std::vector<int> cells;
-    std::vector<float> cand;
+    std::vector<float> cells, cand;
     for (int g = 0; g < 64; g++) e->hullmap_of_geom[g] = -1;
     for (int g = 0; g < model->ngeom; g++) {
       if (model->geom_type[g] != CS_GEOM_MESH || model->geom_hullnum[g] < HM_MIN_VERTS || !hull_vert || !hull_adr || !hull_nbr) continue;
@@ -639,14 +638,15 @@ int cosim_create(const cosim_model_t* model, const float* hull_vert, const int* 
       for (int v = adr; v < adr + num; v++)
         for (int k = hull_adr[v]; k < hull_adr[v + 1]; k++)
           if (k < 0 || k >= model->nhulledge || hull_nbr[k] < 0 || hull_nbr[k] >= num) { delete e; return fail(COSIM_EINVAL, "cosim_create: hull neighbour graph out of range"); }
-      e->hullmap_of_geom[g] = (int)(cells.size() / 2);
+      e->hullmap_of_geom[g] = (int)(cells.size() / (4 * HM_REC));
       build_support_map(hull_vert + 3 * (size_t)adr, num, hull_adr + adr, hull_nbr, cells, cand);
     }
     for (int g = 0; g < 64; g++) e->hm.g_hullmap[g] = e->hullmap_of_geom[g];
-    if (cells.empty()) { cells.assign(2, 0); cand.assign(4, 0.f); }
-    HIP_TRY(hipMalloc(&e->d_hull_cell, cells.size() * sizeof(int)));
+    if (cells.empty()) cells.assign(4 * HM_REC, 0.f);
+    if (cand.empty()) cand.assign(4, 0.f);
+    HIP_TRY(hipMalloc(&e->d_hull_cell, cells.size() * sizeof(float)));
     HIP_TRY(hipMalloc(&e->d_hull_cand, cand.size() * sizeof(float)));
-    HIP_TRY(hipMemcpy(e->d_hull_cell, cells.data(), cells.size() * sizeof(int), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(e->d_hull_cell, cells.data(), cells.size() * sizeof(float), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(e->d_hull_cand, cand.data(), cand.size() * sizeof(float), hipMemcpyHostToDevice));
   }
   HIP_TRY(hipMalloc(&e->d_model, sizeof(DevModel)));
@@ -973,12 +973,12 @@ int cosim_rollout(cosim_engine_t* e, int steps, const float* actions_dev, const 
 int cosim_hull_support_check(const float* verts, int n, const int* adr, const int* nbr, const float* dirs, int ndir, int* out_map_idx,
                              int* out_scan_idx, int* out_stats) {
   if (!verts || !adr || !nbr || !dirs || !out_map_idx || !out_scan_idx || n < 1 || ndir < 0) return fail(COSIM_EINVAL, "cosim_hull_support_check: bad argument");
-  std::vector<int> cells;
-  std::vector<float> cand;
+  std::vector<float> cells, cand;
   build_support_map(verts, n, adr, nbr, cells, cand);
-  int biggest = 0;
-  for (int c = 0; c < HM_CELLS; c++) biggest = cells[2 * c + 1] > biggest ? cells[2 * c + 1] : biggest;
-  if (out_stats) { out_stats[0] = (int)(cand.size() / 4); out_stats[1] = biggest; out_stats[2] = HM_CELLS; }
+  auto as_int = [](float f) { union { int i; float f; } u; u.f = f; return u.i; };
+  int biggest = 0, total = 0;
+  for (int c = 0; c < HM_CELLS; c++) { const int k = as_int(cells[4 * (size_t)HM_REC * c]); biggest = k > biggest ? k : biggest; total += k; }
+  if (out_stats) { out_stats[0] = total; out_stats[1] = biggest; out_stats[2] = HM_CELLS; }
   for (int d = 0; d < ndir; d++) {
     const float* l = dirs + 3 * (size_t)d;
     float best = -3.0e38f;
@@ -988,12 +988,13 @@ int cosim_hull_support_check(const float* verts, int n, const int* adr, const in
       if (t > best) { best = t; bi = i; }
     }
     out_scan_idx[d] = bi;
-    const int c = support_cell(l), start = cells[2 * c], count = cells[2 * c + 1];
+    const float* rec = &cells[4 * (size_t)HM_REC * support_cell(l)];
+    const int count = as_int(rec[0]), ovf = as_int(rec[1]);
     best = -3.0e38f;
     union { int i; float f; } ix;
-    ix.f = cand[4 * (size_t)start + 3];
+    ix.f = rec[4 + 3];
     for (int i = 0; i < count; i++) {
-      const float* x = &cand[4 * (size_t)(start + i)];
+      const float* x = i < HM_INLINE ? rec + 4 * (1 + i) : &cand[4 * (size_t)(ovf + i - HM_INLINE)];
       const float t = l[0] * x[0] + l[1] * x[1] + l[2] * x[2];
       if (t > best) { best = t; ix.f = x[3]; }
     }

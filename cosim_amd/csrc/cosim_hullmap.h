@@ -19,6 +19,8 @@ namespace cosim {
 constexpr int HM_R = 16;                       // cells per cube-face edge
 constexpr int HM_CELLS = 6 * HM_R * HM_R;      // per hull
 constexpr int HM_MIN_VERTS = 32;               // smaller hulls (the 8-vertex boxes) are scanned directly
+constexpr int HM_INLINE = 4;                   // candidates stored in the cell's own record; the rest in the overflow list
+constexpr int HM_REC = 1 + HM_INLINE;          // float4 words per cell record: header (count, overflow start), then HM_INLINE candidates
 
 // cell of a direction given in the hull's own frame (any length; non-finite input lands in some valid cell)
 __host__ __device__ inline int support_cell(const float* l) {
@@ -34,9 +36,11 @@ __host__ __device__ inline int support_cell(const float* l) {
 }
 
 // One hull: `verts` [n][3], CSR neighbour graph (`adr` [n + 1] absolute offsets into `nbr`, neighbour ids local to the hull).
-// Appends HM_CELLS (start, count) pairs to `cells` (start = index into `cand` / 4) and the candidates (x, y, z, vertex index as int
-// bits) to `cand`.
-inline void build_support_map(const float* verts, int n, const int* adr, const int* nbr, std::vector<int>& cells, std::vector<float>& cand) {
+// Appends HM_CELLS records of HM_REC float4 words to `cells`: the header (candidate count, index of the first overflow candidate in
+// `cand` / 4, as int bits) and the first HM_INLINE candidates (x, y, z, vertex index as int bits; unused slots repeat the last one);
+// candidates beyond HM_INLINE go to `cand`.  A query's first trip to memory -- header and inline candidates, one address computed
+// from the cell index alone -- answers most cells (4 candidates on average); only the cells facing a flat side need the second.
+inline void build_support_map(const float* verts, int n, const int* adr, const int* nbr, std::vector<float>& cells, std::vector<float>& cand) {
   constexpr double grow = 2e-3, slack = 1e-4;
   double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
   for (int i = 0; i < n; i++) for (int k = 0; k < 3; k++) { lo[k] = fmin(lo[k], (double)verts[3 * i + k]); hi[k] = fmax(hi[k], (double)verts[3 * i + k]); }
@@ -52,8 +56,7 @@ inline void build_support_map(const float* verts, int n, const int* adr, const i
         P[k][c] = -1.0 + 2.0 * (iv + (k & 1)) / HM_R + ((k & 1) ? grow : -grow);
         pmax = fmax(pmax, sqrt(P[k][0] * P[k][0] + P[k][1] * P[k][1] + P[k][2] * P[k][2]));
       }
-      const int start = (int)(cand.size() / 4);
-      int count = 0;
+      std::vector<int> list;
       for (int v = 0; v < n; v++) {
         bool keep = true;
         for (int e = adr[v]; e < adr[v + 1] && keep; e++) {
@@ -63,23 +66,24 @@ inline void build_support_map(const float* verts, int n, const int* adr, const i
           for (int k = 0; k < 4; k++) m = fmax(m, P[k][0] * w[0] + P[k][1] * w[1] + P[k][2] * w[2]);
           keep = m >= -slack * diam * pmax;
         }
-        if (keep) {
-          union { int i; float f; } ix;
-          ix.i = v;
-          cand.push_back(verts[3 * v]); cand.push_back(verts[3 * v + 1]); cand.push_back(verts[3 * v + 2]); cand.push_back(ix.f);
-          count++;
-        }
+        if (keep) list.push_back(v);
       }
-      if (count == 0) {   // cannot happen for a closed hull (some vertex is the arg max at the cell's centre); keep the table total anyway
+      if (list.empty()) {   // cannot happen for a closed hull (some vertex is the arg max at the cell's centre); keep the table total anyway
         double d[3]; d[a] = s; d[b] = -1.0 + (2.0 * iu + 1.0) / HM_R; d[c] = -1.0 + (2.0 * iv + 1.0) / HM_R;
         int bi = 0; double best = -1e300;
         for (int v = 0; v < n; v++) { const double t = d[0] * verts[3 * v] + d[1] * verts[3 * v + 1] + d[2] * verts[3 * v + 2]; if (t > best) { best = t; bi = v; } }
-        union { int i; float f; } ix;
-        ix.i = bi;
-        cand.push_back(verts[3 * bi]); cand.push_back(verts[3 * bi + 1]); cand.push_back(verts[3 * bi + 2]); cand.push_back(ix.f);
-        count = 1;
+        list.push_back(bi);
       }
-      cells.push_back(start); cells.push_back(count);
+      union { int i; float f; } w0, w1;
+      w0.i = (int)list.size(); w1.i = (int)(cand.size() / 4);
+      cells.push_back(w0.f); cells.push_back(w1.f); cells.push_back(0.f); cells.push_back(0.f);
+      for (int k = 0; k < (int)list.size() || k < HM_INLINE; k++) {
+        const int v = list[k < (int)list.size() ? k : (int)list.size() - 1];
+        union { int i; float f; } ix;
+        ix.i = v;
+        std::vector<float>& dst = k < HM_INLINE ? cells : cand;
+        dst.push_back(verts[3 * v]); dst.push_back(verts[3 * v + 1]); dst.push_back(verts[3 * v + 2]); dst.push_back(ix.f);
+      }
     }
   }
 }

@@ -44,7 +44,7 @@ struct KArgs {
   const float* hull_vert;
   const int* hull_adr;
   const int* hull_nbr;
-  const int2* hull_cell;     // support maps (cosim_hullmap.h): (start, count) per cell, candidates (x, y, z, vertex index)
+  const float4* hull_cell;   // support maps (cosim_hullmap.h): HM_REC words per cell (header, inline candidates); overflow candidates
   const float4* hull_cand;
   const float* hfield;
   const float* hfield_mip;   // highest vertex of each tile of HF_TILE x HF_TILE vertices (row-major, ceil(nrow / HF_TILE) x ceil(ncol / HF_TILE))
@@ -1746,13 +1746,21 @@ __device__ __forceinline__ void env_body(KArgsP kargs_p, const int env, typename
           if (hmap >= 0) {
             // support map (cosim_hullmap.h): the lowest vertex is the support point along -n; the candidates of that cell, one per lane
             const float dn[3] = {-lnv[0], -lnv[1], -lnv[2]};
-            const int2 ce = A.hull_cell[hmap + support_cell(dn)];   // (uniform over the env's LW lanes)
-            const int cn = ce.y;
-            const float4* cp = A.hull_cand + ce.x;
-            for (int i0 = 0; i0 < cn; i0 += LW) {
-              const float4 x = cp[min(i0 + ln, cn - 1)];
-              const float dist = offn + hull_dot(lnv, x);
-              if (i0 + ln < cn && dist < best) { best = dist; besti = __float_as_int(x.w); }
+            const float4* rec = A.hull_cell + (size_t)HM_REC * (hmap + support_cell(dn));   // (uniform over the env's LW lanes)
+            const float4 hd = rec[0], x0 = rec[1 + (ln & (HM_INLINE - 1))];   // one trip: header + inline candidates (lane k < 4: candidate k)
+            const int cn = __float_as_int(hd.x);
+            {
+              const float dist = offn + hull_dot(lnv, x0);
+              if (ln < HM_INLINE && ln < cn) { best = dist; besti = __float_as_int(x0.w); }
+            }
+            if (cn > HM_INLINE) {
+              const float4* cp = A.hull_cand + __float_as_int(hd.y);
+              const int rest = cn - HM_INLINE;
+              for (int i0 = 0; i0 < rest; i0 += LW) {
+                const float4 x = cp[min(i0 + ln, rest - 1)];
+                const float dist = offn + hull_dot(lnv, x);
+                if (i0 + ln < rest && dist < best) { best = dist; besti = __float_as_int(x.w); }
+              }
             }
           } else {
             // four vertices per lane in flight per trip (16 bytes per vertex: one load each)

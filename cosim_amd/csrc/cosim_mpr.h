@@ -29,7 +29,7 @@ struct CObj {            // one convex geom, world pose
   float center[3];       // mjccd_center
 };
 // hull arrays (vertices in body coordinates; CSR neighbour graph, used by the plane-hull routine)
-struct HullGraph { const float* vert; const int* adr; const int* nbr; const int2* cell; const float4* cand; };
+struct HullGraph { const float* vert; const int* adr; const int* nbr; const float4* cell; const float4* cand; };
 typedef double real;   // the portal arithmetic runs in fp64 (ill-conditioned for edge contacts); supports are fp32
 __device__ __forceinline__ real mpr_dot(const real* a, const real* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
 __device__ __forceinline__ void mpr_cross(real* r, const real* a, const real* b) {
@@ -95,17 +95,30 @@ __device__ __forceinline__ void cobj_support(const CObj& o, const HullGraph& H, 
     float4 v;
     if (o.map < 0) v = reinterpret_cast<const float4*>(hull)[o.adr + bi];
     else {
-      const int2 ce = H.cell[o.map + support_cell(l)];
-      const float4* cp = H.cand + ce.x;
-      v = cp[0];
-      for (int i = 0; i < ce.y; i += 4) {
-        float4 x[4];
+      // the cell's record: header and the first HM_INLINE candidates, one trip; the overflow list only where a cell holds more
+      const float4* rec = H.cell + (size_t)HM_REC * (o.map + support_cell(l));
+      float4 x[HM_INLINE];
+      const float4 hd = rec[0];
 #pragma unroll
-        for (int k = 0; k < 4; k++) x[k] = cp[min(i + k, ce.y - 1)];
+      for (int k = 0; k < HM_INLINE; k++) x[k] = rec[1 + k];
+      const int cn = __float_as_int(hd.x);
+      v = x[0];
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-          const float t = hull_dot(l, x[k]);
-          if (i + k < ce.y && t > best) { best = t; v = x[k]; }
+      for (int k = 0; k < HM_INLINE; k++) {
+        const float t = hull_dot(l, x[k]);
+        if (k < cn && t > best) { best = t; v = x[k]; }
+      }
+      if (cn > HM_INLINE) {
+        const float4* cp = H.cand + __float_as_int(hd.y);
+        const int rest = cn - HM_INLINE;
+        for (int i = 0; i < rest; i += 4) {
+#pragma unroll
+          for (int k = 0; k < 4; k++) x[k] = cp[min(i + k, rest - 1)];
+#pragma unroll
+          for (int k = 0; k < 4; k++) {
+            const float t = hull_dot(l, x[k]);
+            if (i + k < rest && t > best) { best = t; v = x[k]; }
+          }
         }
       }
     }
@@ -123,13 +136,21 @@ __device__ __forceinline__ void cobj_support(const CObj& o, const HullGraph& H, 
     if (map >= 0) {
       // support map: the candidates of the direction's cell, one per lane (a few; a cell facing a flat side of the hull holds up
       // to ~90); besti is the vertex's index in the hull, so ties fall like in the scan
-      const int2 ce = H.cell[map + __builtin_amdgcn_readfirstlane(support_cell(l))];
-      const int cn = __builtin_amdgcn_readfirstlane(ce.y);
-      const float4* cp = H.cand + __builtin_amdgcn_readfirstlane(ce.x);
-      for (int i0 = 0; i0 < cn; i0 += 64) {
-        const float4 x = cp[min(i0 + ln, cn - 1)];
-        const float t = hull_dot(l, x);
-        if (i0 + ln < cn && t > best) { best = t; besti = __float_as_int(x.w); bx = x.x; by = x.y; bz = x.z; }
+      const float4* rec = H.cell + (size_t)HM_REC * (map + __builtin_amdgcn_readfirstlane(support_cell(l)));
+      const float4 hd = rec[0], x0 = rec[1 + (ln & (HM_INLINE - 1))];   // one trip: the header and the inline candidates (lane k < 4: candidate k)
+      const int cn = __builtin_amdgcn_readfirstlane(__float_as_int(hd.x));
+      {
+        const float t = hull_dot(l, x0);
+        if (ln < HM_INLINE && ln < cn) { best = t; besti = __float_as_int(x0.w); bx = x0.x; by = x0.y; bz = x0.z; }
+      }
+      if (cn > HM_INLINE) {
+        const float4* cp = H.cand + __builtin_amdgcn_readfirstlane(__float_as_int(hd.y));
+        const int rest = cn - HM_INLINE;
+        for (int i0 = 0; i0 < rest; i0 += 64) {
+          const float4 x = cp[min(i0 + ln, rest - 1)];
+          const float t = hull_dot(l, x);
+          if (i0 + ln < rest && t > best) { best = t; besti = __float_as_int(x.w); bx = x.x; by = x.y; bz = x.z; }
+        }
       }
     } else
     for (int i0 = 0; i0 < num; i0 += 64 * COOP_K) {
@@ -189,23 +210,34 @@ __device__ __forceinline__ void cobj_box_coop(const CObj& o, const HullGraph& H,
   if (map >= 0) {
     // support map: six cells, their candidates one per lane, all six loads in flight together
     int cb[6], cn[6], nmax = 0;
+    {
+      float4 hd[6], x[6];   // one trip: six headers and the inline candidates (lane k < 4: candidate k of each cell)
 #pragma unroll
-    for (int s = 0; s < 6; s++) {
-      const float d[3] = {(s & 1) ? -l[s >> 1][0] : l[s >> 1][0], (s & 1) ? -l[s >> 1][1] : l[s >> 1][1], (s & 1) ? -l[s >> 1][2] : l[s >> 1][2]};
-      const int2 ce = H.cell[map + __builtin_amdgcn_readfirstlane(support_cell(d))];
-      cb[s] = __builtin_amdgcn_readfirstlane(ce.x); cn[s] = __builtin_amdgcn_readfirstlane(ce.y);
-      nmax = max(nmax, cn[s]);
+      for (int s = 0; s < 6; s++) {
+        const float d[3] = {(s & 1) ? -l[s >> 1][0] : l[s >> 1][0], (s & 1) ? -l[s >> 1][1] : l[s >> 1][1], (s & 1) ? -l[s >> 1][2] : l[s >> 1][2]};
+        const float4* rec = H.cell + (size_t)HM_REC * (map + __builtin_amdgcn_readfirstlane(support_cell(d)));
+        hd[s] = rec[0]; x[s] = rec[1 + (ln & (HM_INLINE - 1))];
+      }
+#pragma unroll
+      for (int s = 0; s < 6; s++) {
+        cn[s] = __builtin_amdgcn_readfirstlane(__float_as_int(hd[s].x)); cb[s] = __builtin_amdgcn_readfirstlane(__float_as_int(hd[s].y));
+        nmax = max(nmax, cn[s] - HM_INLINE);
+        const int a = s >> 1;
+        const float t0 = hull_dot(l[a], x[s]);
+        const float t = (s & 1) ? -t0 : t0;
+        if (ln < HM_INLINE && ln < cn[s]) { best[s] = t; besti[s] = __float_as_int(x[s].w); bv[s][0] = x[s].x; bv[s][1] = x[s].y; bv[s][2] = x[s].z; }
+      }
     }
-    for (int i0 = 0; i0 < nmax; i0 += 64) {
+    for (int i0 = 0; i0 < nmax; i0 += 64) {   // overflow lists (cells facing a flat side of the hull)
       float4 x[6];
 #pragma unroll
-      for (int s = 0; s < 6; s++) x[s] = H.cand[cb[s] + min(i0 + ln, cn[s] - 1)];
+      for (int s = 0; s < 6; s++) x[s] = H.cand[cb[s] + min(i0 + ln, max(cn[s] - HM_INLINE, 1) - 1)];
 #pragma unroll
       for (int s = 0; s < 6; s++) {
         const int a = s >> 1;
         const float t0 = hull_dot(l[a], x[s]);
         const float t = (s & 1) ? -t0 : t0;
-        if (i0 + ln < cn[s] && t > best[s]) { best[s] = t; besti[s] = __float_as_int(x[s].w); bv[s][0] = x[s].x; bv[s][1] = x[s].y; bv[s][2] = x[s].z; }
+        if (i0 + ln < cn[s] - HM_INLINE && t > best[s]) { best[s] = t; besti[s] = __float_as_int(x[s].w); bv[s][0] = x[s].x; bv[s][1] = x[s].y; bv[s][2] = x[s].z; }
       }
     }
   } else
