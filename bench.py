@@ -39,6 +39,7 @@ ROBOT = "flamingo_light_v1"
 HBM_PEAK_GBS = 8000.0
 # name -> (robot, terrain, height_map, envs per GPU).  The default ("light_flat") is BASELINE.json configs[1], the
 # configuration the metric is quoted on; the others are the remaining BASELINE configs, selectable for DESIGN.md numbers.
+TIMING_STRIDE = 5
 WORKLOADS = {
     "light_flat": ("flamingo_light_v1", "flat", False, 4096),
     "light_rocky": ("flamingo_light_v1", "rocky_hard", False, 4096),
@@ -394,6 +395,11 @@ def main(argv=None):
     reporter.acc.reduce()                 # warm-up of the torch kernels behind reduce(), then start from zero
     reporter.acc.buf.zero_()
     torch.cuda.synchronize()
+    # kernel duration for the roofline: HIP event pairs around every TIMING_STRIDE-th launch of the timed region, on the launch's own
+    # stream (an event pair around EVERY launch costs the pipeline 4 % of a 20-step run: tools/gpu_shortrun.py; 5 is coprime with the
+    # four ranges, so every range is sampled in turn)
+    for e_ in envs:
+        e_.engine.set_param("timing_stride", np.array([float(TIMING_STRIDE)], dtype=np.float32))
     env.engine.set_timing(True)
 
     def sync():
@@ -410,15 +416,19 @@ def main(argv=None):
     env.join()                                          # the deferred join: the caller's stream now waits for every range
     torch.cuda.synchronize()
     t_gpu = time.perf_counter()
-    fleet = reporter.acc.reduce()                       # the one collective: RCCL all-reduce of (count, sum, sum^2)
     sync()
     dt = time.perf_counter() - t0
+    # the one collective, after the K steps: RCCL all-reduce of the reporter's (count, sum, sum^2) accumulated during them (the per-step
+    # accumulation kernels run inside the timed region, on the range streams)
+    fleet = reporter.acc.reduce()
+    torch.cuda.synchronize()
     if os.environ.get("COSIM_BENCH_TRACE"):             # diagnostic: where the timed region's wall time went
-        print(f"[bench trace] issue loop {1e3 * (t_issue - t0):.3f} ms, + join/sync {1e3 * (t_gpu - t_issue):.3f} ms, + reduce/sync "
+        print(f"[bench trace] issue loop {1e3 * (t_issue - t0):.3f} ms, + join/sync {1e3 * (t_gpu - t_issue):.3f} ms, + barrier/sync "
               f"{1e3 * (t0 + dt - t_gpu):.3f} ms", file=sys.stderr, flush=True)
     kt = [e.engine.kernel_time() for e in envs]
-    launches = sum(k[1] for k in kt)
-    kernel_ms = sum(k[0] * k[1] for k in kt) / max(1, launches)
+    timed_launches = sum(k[1] for k in kt)                       # the sampled ones (an event pair each)
+    kernel_ms = sum(k[0] * k[1] for k in kt) / max(1, timed_launches)
+    launches = S * args.steps                                     # range launches of the timed region on this rank
     for e in envs:
         e.engine.set_timing(False)
     finite = all(bool(torch.isfinite(e.state).all().item()) for e in envs)
@@ -491,7 +501,8 @@ def main(argv=None):
                          "kernel": (f"cosim::env_kernel<{env.nv},{env.cm.blob.nbody},...>" if not split_waves else
                                     f"cosim::env_narrow_kernel + env_step_kernel<{env.nv},{env.cm.blob.nbody},...>: one pair of launches per substep, "
                                     f"{split_waves} narrowphase waves per env; kernel_ms is the whole control step's launches on one range stream"),
-                         "kernel_ms": kernel_ms, "launches": launches,
+                         "kernel_ms": kernel_ms, "launches": launches, "timed_launches": timed_launches,
+                         "launches_note": f"kernel_ms is the mean over every {TIMING_STRIDE}th launch of the timed region (a HIP event pair each)",
                          "algorithmic_bytes_per_env_step": balg,
                          "note": "latency/VALU-bound small-state solver; HBM sees only the compulsory state traffic (SURVEY §8d)"},
         }

@@ -53,6 +53,8 @@ struct cosim_engine {
   int max_ls = 24;
   int nsub_override = 0;
   int pair_coop = 1;
+  int timing_stride = 1;   // kernel timing: an event pair around every n-th launch (the events themselves cost ~4 % of a short run at 1)
+  unsigned launch_seq = 0;
   int block_cull = 1;
   int coop_walk = 0;
   int pair_boxbox = 1;
@@ -822,6 +824,7 @@ int cosim_set_param(cosim_engine_t* e, const char* name, const float* host, int 
     }
     return COSIM_OK;
   }
+  else if (n == "timing_stride") { e->timing_stride = (int)host[0] >= 1 ? (int)host[0] : 1; return COSIM_OK; }   // time every n-th launch
   else if (n == "coop_walk") { e->coop_walk = (int)host[0] != 0; return COSIM_OK; }   // 1: the round-2 cooperative walk of hulls with few prisms under them (A/B)
   else if (n == "block_cull") { e->block_cull = (int)host[0] != 0; return COSIM_OK; }   // narrowphase kernel's block tests (default 1); 0 for A/B runs and tests
   else if (n == "boxbox_mode") { e->pair_boxbox = (int)host[0] != 0; return COSIM_OK; }   // 1: box-box pairs through mjc_BoxBox (default), 0: through MPR
@@ -1043,7 +1046,7 @@ int cosim_step_range(cosim_engine_t* e, int first, int count, const float* actio
   hipStream_t s = (hipStream_t)stream;
   // kernel timing: one HIP event pair per launch on the launch stream, read back in cosim_kernel_time() (no sync here)
   int slot = -1;
-  if (e->timing) {
+  if (e->timing && (e->launch_seq++ % (unsigned)e->timing_stride) == 0) {
     if (e->ev_used + 2 > (int)e->ev.size()) {
       if (e->ev.size() >= 4096) { int rc2 = drain_events(e); if (rc2) return rc2; }
       else for (int i = 0; i < 2; i++) { hipEvent_t x; HIP_TRY(hipEventCreate(&x)); e->ev.push_back(x); }

@@ -95,6 +95,8 @@ int cosim_query(const cosim_engine_t* e, const char* name);
  * large-capacity fix-up launches off: contacts beyond the fleet kernel's slots are then left out and counted), "support_map" (1,
  * default: support queries on mesh geoms with 32 or more hull vertices go through the hull's support map -- the few vertices that can
  * win in the direction's cube-map cell, same arg max as the scan; 0: every query scans the whole hull, for A/B runs and tests),
+ * "timing_stride" (default 1: with cosim_set_timing on, an event pair around every launch; n: around every n-th launch -- the
+ * events cost ~4 % of a 20-step run at 1, choose n coprime with "ranges" so that every range is sampled),
  * "block_cull" (1, default: the narrowphase kernel of the split pipeline tests blocks of 8 prisms -- height and oriented box -- before
  * their prisms; 0: every block goes on to the per-prism tests; same contacts either way).
  * cosim_query additionally answers "contact_slots" / "pair_slots" (capacity of the selected kernel variant: heightfields with cells
