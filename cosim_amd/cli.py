@@ -58,6 +58,9 @@ def main(argv=None) -> int:
     ap.add_argument("--trace-env", type=int, default=None, help="also keep the per-step info series of this local env")
     ap.add_argument("--percentiles", action="store_true", help="p5 / p50 / p95 of tracking error, |torque| and action-RMSE in the report")
     ap.add_argument("--graph", action="store_true", help="capture policy -> step -> report in a HIP graph and replay it (ONNX policies)")
+    ap.add_argument("--pipelined", action="store_true",
+                    help="policy -> step -> report per env range on the range's own stream, no fleet-wide barrier per step (ONNX MLP policies)")
+    ap.add_argument("--ranges", type=int, default=4, help="env ranges of --pipelined")
     ap.add_argument("--backend", default="nccl")
     args = ap.parse_args(argv)
 
@@ -127,7 +130,8 @@ def main(argv=None) -> int:
                 cfg[section][k].update(v)
             else:
                 cfg[section][k] = v
-    env = BatchedEnv(cfg, num_envs=hi - lo, device=dev, seed=args.seed, auto_reset=True, env_id0=lo)
+    env = BatchedEnv(cfg, num_envs=hi - lo, device=dev, seed=args.seed, auto_reset=True, env_id0=lo,
+                     **({"ranges": args.ranges, "deferred_join": True} if args.pipelined else {}))
     if args.policy == "sinusoid":
         policy = SinusoidPolicy(env.num_envs, env.action_dim, env.device, env_id0=lo, seed=args.seed)
     else:
@@ -142,6 +146,8 @@ def main(argv=None) -> int:
                  "graph would replay one frozen action")
     if args.graph and (pushes or len(commands) > 1 or args.trace_env >= 0):
         ap.error("--graph replays one captured control step: pushes, command changes and --trace-env need the eager loop")
+    if args.pipelined and (not hasattr(policy, "get_action_into") or args.graph or args.trace_env >= 0):
+        ap.error("--pipelined needs an ONNX MLP policy (random-mlp or a file) and excludes --graph / --trace-env")
     rep = FleetReporter(env, trace_env=args.trace_env if args.trace_env >= 0 else None, percentiles=args.percentiles)
     run = Runner(env, policy, reporter=rep)
     for i, v in enumerate(commands[0][1:1 + env.command_dim]):
@@ -163,7 +169,12 @@ def main(argv=None) -> int:
         rep.note_done(terminated, truncated)
     torch.cuda.synchronize(env.device)
     t0 = time.perf_counter()
-    n = run.test_graphed(args.steps) if args.graph else run.test(max_steps=args.steps, on_step=on_step, before_step=before_step)
+    if args.pipelined:
+        if pushes or len(commands) > 1:
+            ap.error("--pipelined runs one command and no push schedule (use Runner.test_pipelined with update_command for more)")
+        n = run.test_pipelined(args.steps)
+    else:
+        n = run.test_graphed(args.steps) if args.graph else run.test(max_steps=args.steps, on_step=on_step, before_step=before_step)
     torch.cuda.synchronize(env.device)
     dt = time.perf_counter() - t0
     out = rep.save(args.report) if (args.report and rank == 0) else rep.summary()

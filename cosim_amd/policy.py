@@ -384,6 +384,19 @@ class MLPPolicy:
         return out.squeeze(0) if single else out
 
 
+    def get_action_into(self, state_rows, out_rows):
+        """``out_rows[:] = get_action(state_rows)`` on the CURRENT stream without allocating: for callers that evaluate the policy per
+        env range on the range's own stream (``Runner.test_pipelined``).  Both are contiguous row slices of ``[N, ...]`` tensors."""
+        f = self._fused
+        if f is None or state_rows.shape[1] != f["in_dim"] or not (state_rows.is_contiguous() and out_rows.is_contiguous()):
+            out_rows.copy_(self.get_action(state_rows))
+            return
+        rc = f["L"].cosim_mlp_forward(state_rows.data_ptr(), state_rows.shape[0], f["nl"], f["dims"], f["w"], f["b"], f["act"], f["alpha"], 1.0,
+                                      out_rows.data_ptr(), self.torch.cuda.current_stream(self.device).cuda_stream)
+        if rc != 0:
+            raise RuntimeError(f["L"].cosim_last_error().decode())
+
+
 class LSTMPolicy:
     """``core/policy.py:24-47``: inputs (state, "h_in", "c_in"), outputs (action, h_out, c_out); h/c kept per env."""
 

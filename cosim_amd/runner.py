@@ -93,6 +93,64 @@ class Runner:
                 done_all = bool(done_seen.all().item())
         return steps
 
+    def test_pipelined(self, max_steps: int, report_every: int = 1, inflight: int = 2) -> int:
+        """The same loop -- policy -> step -> reporter, ``core/tester.py:66-97`` -- with NO fleet-wide barrier per step: the env was
+        built with ``ranges=S`` (S > 1), and each range of envs runs its own chain policy(range) -> step(range) -> reporter(range) on
+        the range's own stream (``BatchedEnv.range_streams``).  A range's next control step then fills the tail of the others'
+        launches, as in the bench; the policy only ever needs the states of its own range.  Needs an auto-reset env, a stateless
+        device policy with ``get_action_into`` (``policy.MLPPolicy``) and a ``FleetReporter`` (or none).  The user command and a held
+        push are read before each step like in ``test`` (changing them joins the ranges first).  ``inflight``: how many steps the host
+        may run ahead of each range (deep queues step slower)."""
+        env, t = self.env, self.env.torch
+        if len(env.range_list) < 2:
+            raise ValueError("test_pipelined needs an env built with ranges > 1")
+        if not env.auto_reset:
+            raise ValueError("test_pipelined needs auto_reset=True (no per-step host check of the done flags)")
+        if not hasattr(self.policy, "get_action_into") or not getattr(self.policy, "graph_safe", False):
+            raise ValueError(f"test_pipelined: {type(self.policy).__name__} cannot be evaluated per range on a stream of its own "
+                             "(needs get_action_into and no per-env or host-side state); use Runner.test")
+        if self.reporter is not None and not hasattr(self.reporter, "write_info_range"):
+            raise ValueError("test_pipelined: the reporter must reduce per range (reporter.FleetReporter)")
+        env.reset()
+        episodes0 = env.solver_stats()["episodes_ended"]
+        env.receive_user_command(self.user_command)
+        last_cmd = self.user_command.copy()
+        action = t.zeros((env.num_envs, env.action_dim), dtype=t.float32, device=env.device)
+        cur = t.cuda.current_stream(env.device)
+        for st in env.range_streams:
+            st.wait_stream(cur)                                    # the reset, the command upload and `action` are ready
+        ring = [[t.cuda.Event() for _ in range(max(inflight, 1))] for _ in env.range_list]
+        steps = 0
+        while steps < max_steps and not self._stop:
+            if self._push_event or not np.array_equal(last_cmd, self.user_command):
+                env.join()                                         # whole-fleet inputs change: the ranges meet here
+                t.cuda.current_stream(env.device).synchronize()
+                env.receive_user_command(self.user_command)
+                last_cmd = self.user_command.copy()
+                if self._push_event:
+                    env.event("push", self._push_vel)
+                cur = t.cuda.current_stream(env.device)
+                for st in env.range_streams:
+                    st.wait_stream(cur)
+            sample = self.reporter is not None and steps % report_every == 0
+            for i, (first, count) in enumerate(env.range_list):
+                if inflight > 0 and steps >= inflight:
+                    ring[i][steps % inflight].synchronize()
+                with t.cuda.stream(env.range_streams[i]):
+                    self.policy.get_action_into(env.state[first:first + count], action[first:first + count])   # tester.py:70
+                    env.step_range(first, count, action)                                                          # :90
+                    if sample:
+                        self.reporter.write_info_range(first, count)                                              # :92
+                    if inflight > 0:
+                        ring[i][steps % inflight].record()
+                env.range_mark(i)
+            steps += 1
+        env.join()
+        t.cuda.current_stream(env.device).synchronize()
+        if self.reporter is not None and hasattr(self.reporter, "episodes_ended"):
+            self.reporter.episodes_ended = env.solver_stats()["episodes_ended"] - episodes0
+        return steps
+
     def test_graphed(self, max_steps: int, warmup: int = 3) -> int:
         """The same loop with one control step (policy -> step -> reporter update) captured in a HIP graph and replayed:
         the per-step host work of ~40 small launches collapses into one graph launch.  Needs an auto-reset env, a policy

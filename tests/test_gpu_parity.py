@@ -1167,6 +1167,45 @@ def test_graph_captured_rollout_equals_eager(tmp_path):
     assert m0["abs_torque_0"]["mean"] == pytest.approx(m1["abs_torque_0"]["mean"], rel=1e-12)
 
 
+def test_pipelined_runner_equals_the_eager_loop(tmp_path):
+    """Runner.test_pipelined -- policy -> step -> report per env range on the range's own stream, no fleet-wide barrier per step --
+    against Runner.test: a policy row depends on its env's state only, so the fleet ends in the same bits, and the fleet report
+    (atomics into one accumulator, order-dependent in the last bits) in the same means.  A command change in mid-run joins the
+    ranges and takes effect at the same step."""
+    import torch
+    from cosim_amd.batched_env import BatchedEnv
+    from cosim_amd.config import make_config
+    from cosim_amd.policy import MLPPolicy, write_random_mlp
+    from cosim_amd.reporter import FleetReporter
+    from cosim_amd.runner import Runner
+    n = 256
+    cfg = make_config("flamingo_light_v1", num_envs=n, seed=7, max_duration=1.0)       # 50-step episodes: auto-reset inside the run
+    path = str(tmp_path / "actor.onnx")
+    outs = []
+    for pipelined in (False, True):
+        env = BatchedEnv(cfg, num_envs=n, seed=7, auto_reset=True, **({"ranges": 4, "deferred_join": True} if pipelined else {}))
+        if not pipelined:
+            write_random_mlp(path, env.state_dim, env.action_dim, hidden=(64, 64), seed=5)
+        rep = FleetReporter(env)
+        run = Runner(env, MLPPolicy(path, device=env.device), reporter=rep)
+        run.update_command(0, 0.5)
+        if pipelined:
+            assert run.test_pipelined(40) == 40
+        else:
+            assert run.test(max_steps=40) == 40
+        run.update_command(0, -0.3)                                 # (a second leg from a fresh reset, another command)
+        k = run.test_pipelined(70) if pipelined else run.test(max_steps=70)
+        assert k == 70
+        torch.cuda.synchronize()
+        outs.append((env.state.clone(), env.get_data().qpos.clone(), rep.summary(), env.solver_stats()["episodes_ended"]))
+        env.close()
+    assert outs[0][3] == outs[1][3] >= n                           # the time limit fired inside the second leg
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    m0, m1 = outs[0][2]["metrics"], outs[1][2]["metrics"]
+    assert m0["lin_vel_x"]["count"] == m1["lin_vel_x"]["count"] == n * 110
+    assert m0["abs_torque_0"]["mean"] == pytest.approx(m1["abs_torque_0"]["mean"], rel=1e-9)
+
+
 def test_non_finite_state_resets_only_that_env(parity):
     """mj_checkPos / mj_checkVel / mj_checkAcc (mj_step resets the data on a bad state): a NaN in one env ends and restarts
     that env inside the step, is counted, and leaves its neighbours bit-identical to a run without the fault."""
