@@ -1180,15 +1180,20 @@ int cosim_debug_support(cosim_engine_t* e, int geom, const float* dirs_host, int
   if (e->hm.rec[geom].g_type != CS_GEOM_MESH) return fail(COSIM_EINVAL, "cosim_debug_support: not a mesh geom");
   HIP_TRY(hipSetDevice(e->device));
   float *d_dirs = nullptr, *d_out = nullptr;
-  HIP_TRY(hipMalloc(&d_dirs, (size_t)n_dirs * 3 * sizeof(float)));
-  HIP_TRY(hipMalloc(&d_out, (size_t)n_dirs * 6 * sizeof(float)));
-  HIP_TRY(hipMemcpy(d_dirs, dirs_host, (size_t)n_dirs * 3 * sizeof(float), hipMemcpyHostToDevice));
-  const HullGraph H{e->d_hull_vert, e->d_hull_adr, e->d_hull_nbr, e->d_hull_cell, e->d_hull_cand};
-  hipLaunchKernelGGL(support_probe_kernel, dim3((n_dirs + 63) / 64), dim3(64), 0, 0, e->d_model, H, geom, d_dirs, n_dirs, d_out, use_map);
-  HIP_TRY(hipGetLastError());
-  HIP_TRY(hipDeviceSynchronize());
-  HIP_TRY(hipMemcpy(out_host, d_out, (size_t)n_dirs * 6 * sizeof(float), hipMemcpyDeviceToHost));
-  hipFree(d_dirs); hipFree(d_out);
+  auto run = [&]() -> hipError_t {   // (one exit, so that the two scratch buffers are released on every path)
+    hipError_t r;
+    if ((r = hipMalloc(&d_dirs, (size_t)n_dirs * 3 * sizeof(float))) != hipSuccess) return r;
+    if ((r = hipMalloc(&d_out, (size_t)n_dirs * 6 * sizeof(float))) != hipSuccess) return r;
+    if ((r = hipMemcpy(d_dirs, dirs_host, (size_t)n_dirs * 3 * sizeof(float), hipMemcpyHostToDevice)) != hipSuccess) return r;
+    const HullGraph H{e->d_hull_vert, e->d_hull_adr, e->d_hull_nbr, e->d_hull_cell, e->d_hull_cand};
+    hipLaunchKernelGGL(support_probe_kernel, dim3((n_dirs + 63) / 64), dim3(64), 0, 0, e->d_model, H, geom, d_dirs, n_dirs, d_out, use_map);
+    if ((r = hipGetLastError()) != hipSuccess) return r;
+    if ((r = hipDeviceSynchronize()) != hipSuccess) return r;
+    return hipMemcpy(out_host, d_out, (size_t)n_dirs * 6 * sizeof(float), hipMemcpyDeviceToHost);
+  };
+  const hipError_t r = run();
+  (void)hipFree(d_dirs); (void)hipFree(d_out);
+  if (r != hipSuccess) return fail(COSIM_EHIP, std::string("cosim_debug_support: ") + hipGetErrorString(r));
   return COSIM_OK;
 }
 
