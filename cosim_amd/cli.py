@@ -165,9 +165,12 @@ def main(argv=None) -> int:
         else:
             run.deactivate_push_event()
 
-    def on_step(k, state, terminated, truncated, info):
-        rep.note_done(terminated, truncated)
+    # episodes ended are counted on the device (engine meta word 11) and read once after the run: a per-step `.item()` on the done
+    # flags would drain the GPU queue at every control step
+    on_step = None
+    episodes0 = None
     torch.cuda.synchronize(env.device)
+    episodes0 = env.solver_stats()["episodes_ended"]
     t0 = time.perf_counter()
     if args.pipelined:
         if pushes or len(commands) > 1:
@@ -177,6 +180,7 @@ def main(argv=None) -> int:
         n = run.test_graphed(args.steps) if args.graph else run.test(max_steps=args.steps, on_step=on_step, before_step=before_step)
     torch.cuda.synchronize(env.device)
     dt = time.perf_counter() - t0
+    rep.episodes_ended = env.solver_stats()["episodes_ended"] - episodes0
     out = rep.save(args.report) if (args.report and rank == 0) else rep.summary()
     if rank == 0:
         print(json.dumps({"env": args.env, "terrain": args.terrain, "envs_total": args.num_envs, "ranks": world, "control_steps": n,
