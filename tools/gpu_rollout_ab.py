@@ -14,6 +14,10 @@ cfg = workload_config(wl, N)
 for ranges in (1, 2, 4):
     env = BatchedEnv(cfg, num_envs=N, seed=1234, auto_reset=True, gain_noise=0.1, ranges=ranges, deferred_join=ranges > 1)
     acts = synthetic_actions(N, 0, 50 + 2 * K, env.action_dim, env.device)
+    if env.engine.query("rollout") != 1:
+        print(f"{wl}: no rollout kernel for this model / terrain (flat flamingo_light_v1 / flamingo_p_v3 only)")
+        env.close()
+        break
     env.reset()
     for t in range(50):
         env.step(acts[t])
